@@ -1,0 +1,171 @@
+/*
+ * rrt.h -- C ABI of librrt_hip.so, the MI355X (gfx950) implementation of the
+ * per-pixel geodesic ray-march hot path of levi2234/RelativisticRayTracer.
+ *
+ * This is the drop-in boundary.  The one entry point of the reference's path is
+ *
+ *     void launch_raymarch(uchar4* d_out, int w, int h, float time,
+ *                          CameraState cam, cudaTextureObject_t skyboxTex,
+ *                          CameraEffects effects);
+ *                                   -- reference include/raymarcher.h:19,
+ *                                      defined src/raymarcher.cu:176-180,
+ *                                      called from src/main.cpp:467
+ *
+ * `include/raymarcher.h` of this repo re-declares it source-compatibly (C++)
+ * as an inline wrapper over rrt_launch_raymarch() below; everything here is
+ * plain C: pointers, ints, floats and PODs -- no HIP or torch types.
+ *
+ * Conventions
+ *   - every function returns an rrt_status (0 = RRT_OK); nothing throws;
+ *   - `d_*` pointers are DEVICE pointers owned by the caller;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *     launches are asynchronous exactly like the reference's (raymarcher.cu:179);
+ *   - the library keeps no per-call state and allocates nothing in a launch,
+ *     so launches may be captured into a hipGraph.
+ */
+#ifndef RRT_H
+#define RRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRT_ABI_VERSION 1
+
+typedef enum {
+    RRT_OK = 0,
+    RRT_ERR_INVALID_ARGUMENT = 1,
+    RRT_ERR_NO_DEVICE = 2,
+    RRT_ERR_HIP = 3,          /* a HIP runtime call failed; see rrt_last_hip_error() */
+    RRT_ERR_BAD_HANDLE = 4,
+    RRT_ERR_OUT_OF_MEMORY = 5
+} rrt_status;
+
+/* Camera basis handed to the kernel.  Layout == reference `struct CameraState`
+ * (include/raymarcher.h:11-16): four packed float3, 48 bytes. */
+typedef struct rrt_camera {
+    float pos[3];
+    float forward[3];
+    float right[3];
+    float up[3];
+} rrt_camera;
+
+/* Per-pixel camera effects.  Layout == reference `struct CameraEffects`
+ * (include/camera_effects/camera_settings.h:4-17): 36 bytes, bools padded to
+ * 4-byte slots (offsets 0,4,8,12,16,20,24,28,32). */
+typedef struct rrt_effects {
+    uint8_t use_bloom;       uint8_t _pad0[3];
+    float bloom_threshold;
+    float bloom_intensity;
+    uint8_t use_vignette;    uint8_t _pad1[3];
+    float vignette_intensity;
+    uint8_t use_chromatic_aberration; uint8_t _pad2[3];
+    float ca_amount;
+    uint8_t use_lens_distortion;      uint8_t _pad3[3];
+    float distortion_amount;
+} rrt_effects;
+
+/* Scene / quality parameters.  Defaults == the reference's compile-time
+ * constants (include/config.h:18-48); `spin` replaces the SPIN_A macro
+ * (config.h:21) so that Kerr a=0.9 / 0.99 are run-time settings. */
+typedef struct rrt_params {
+    float spin;              /* SPIN_A            config.h:21  default 0.0  */
+    int32_t max_steps;       /* MAX_STEPS         config.h:48  default 2000 */
+    int32_t volumetrics;     /* 1 = full disk + dust (reference behaviour);
+                                0 = "skybox only": both densities read 0,
+                                zone-dependent step sizes unchanged        */
+    int32_t sky_frac_bits;   /* bilinear weight bits of the sky sampler:
+                                8 = CUDA-texture-like (default), 0 = exact  */
+    int32_t reserved[4];     /* must be 0 */
+} rrt_params;
+
+/* Opaque sky-texture handle; stands in for cudaTextureObject_t
+ * (`unsigned long long`, reference src/main.cpp:231-263). */
+typedef unsigned long long rrt_sky_t;
+
+/* Optional per-ray outputs of rrt_launch_raymarch_ex (device pointers, any may
+ * be NULL).  Indexing: `ldr`/`hdr` like the RGBA8 frame (bottom-up rows,
+ * raymarcher.cu:168); the others top-down, y*width + x. */
+typedef struct rrt_debug_outputs {
+    float* d_ldr;            /* 4 floats/pixel: tone-mapped r,g,b before the u8 cast, 1 */
+    float* d_hdr;            /* 4 floats/pixel: final_hdr after post-FX, 1              */
+    int32_t* d_steps;        /* RK4 steps taken                                         */
+    int32_t* d_hit;          /* 1 = ray ended on the horizon                            */
+    float* d_pos;            /* 3 floats/pixel: final position                          */
+    float* d_vel;            /* 3 floats/pixel: final velocity                          */
+    float* d_rad;            /* 4 floats/pixel: intensity r,g,b and transmittance       */
+} rrt_debug_outputs;
+
+/* ---- library ---- */
+int rrt_abi_version(void);
+const char* rrt_status_string(int status);
+const char* rrt_last_hip_error(void);          /* thread-local text of the last HIP failure */
+int rrt_device_count(int* count);
+int rrt_params_default(rrt_params* prm);       /* config.h defaults                        */
+int rrt_effects_default(rrt_effects* fx);      /* camera_settings.h:5-16 defaults          */
+
+/* ---- sky texture: replaces loadSkybox()'s cudaMallocArray + texture object,
+ *      reference src/main.cpp:246-263.  RGBA8, row 0 = top of the panorama. ---- */
+int rrt_sky_create(const uint8_t* rgba8_host, int width, int height, rrt_sky_t* out);
+int rrt_sky_create_from_device(const void* d_rgba8, int width, int height, rrt_sky_t* out); /* borrows */
+int rrt_sky_destroy(rrt_sky_t sky);
+
+/* ---- the hot path.  Replaces launch_raymarch, reference include/raymarcher.h:19 /
+ *      src/raymarcher.cu:176-180.  Writes width*height RGBA8 pixels, alpha 255,
+ *      bottom-up rows, to d_out_rgba8.  prm == NULL -> config.h defaults. ---- */
+int rrt_launch_raymarch(void* d_out_rgba8, int width, int height, float time,
+                        const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx,
+                        const rrt_params* prm, void* stream);
+
+/* Row-range variant for sharding the image plane (no counterpart in the
+ * reference, which is single-GPU): renders image rows y0 <= y < y1 (y as in
+ * raymarcher.cu:17, i.e. before the bottom-up flip) of the full width x height
+ * frame.  d_out_rows receives (y1-y0)*width pixels; local row k holds image
+ * row y1-1-k, so concatenating the shards in DESCENDING y order reproduces the
+ * full bottom-up frame. */
+int rrt_launch_raymarch_rows(void* d_out_rows, int width, int height, int y0, int y1, float time,
+                             const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx,
+                             const rrt_params* prm, void* stream);
+
+/* Interleaved row-tile variant: tile t = image rows [t*tile_rows, (t+1)*tile_rows)
+ * belongs to shard (t mod n_shards).  Renders all tiles of `shard` into
+ * d_out_tiles, tile-major in increasing t, each tile stored bottom-up like
+ * rrt_launch_raymarch_rows.  rrt_tile_shard_bytes() gives the buffer size. */
+int rrt_launch_raymarch_tiles(void* d_out_tiles, int width, int height, int tile_rows,
+                              int shard, int n_shards, float time,
+                              const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx,
+                              const rrt_params* prm, void* stream);
+int rrt_tile_shard_rows(int height, int tile_rows, int shard, int n_shards, int* rows);
+/* Scatter one shard's tile buffer into a full bottom-up frame (device to device). */
+int rrt_assemble_tiles(void* d_frame_rgba8, const void* d_tiles, int width, int height,
+                       int tile_rows, int shard, int n_shards, void* stream);
+
+/* Full-frame launch that also fills per-ray debug outputs (parity tests). */
+int rrt_launch_raymarch_ex(void* d_out_rgba8, int width, int height, float time,
+                           const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx,
+                           const rrt_params* prm, const rrt_debug_outputs* dbg, void* stream);
+
+/* ---- unit kernels: the device functions of the path on arrays, for parity
+ *      tests against the oracle (device pointers, n elements, xyz interleaved). ---- */
+int rrt_unit_geodesic_acc(int n, const float* d_p, const float* d_v, float spin, float* d_out, void* stream);
+int rrt_unit_rk4(int n, float* d_p, float* d_v, const float* d_h, float spin, void* stream);
+int rrt_unit_hash31(int n, const float* d_p, float* d_out, void* stream);
+int rrt_unit_noise3d(int n, const float* d_p, float* d_out, void* stream);
+int rrt_unit_fbm(int n, const float* d_p, int octaves, float* d_out, void* stream);
+int rrt_unit_accretion_density(int n, const float* d_p, float time, float* d_out, void* stream);
+int rrt_unit_dust_density(int n, const float* d_p, float time, float* d_out, void* stream);
+int rrt_unit_redshift(int n, const float* d_p, const float* d_vel, float spin, float* d_out, void* stream);
+int rrt_unit_math(int fn, int n, const float* d_a, const float* d_b, float* d_out, void* stream);
+int rrt_unit_sky_sample(int n, const float* d_dir, float off, rrt_sky_t sky, int frac_bits,
+                        float* d_out_rgba, void* stream);
+
+/* ---- host-side camera helpers (C++ in the reference, src/main.cpp:141-167) ---- */
+int rrt_camera_from_angles(const float pos[3], float yaw_deg, float pitch_deg, rrt_camera* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRT_H */

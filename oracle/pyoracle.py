@@ -1,0 +1,285 @@
+"""ctypes binding of the CPU oracle (oracle/librrt_oracle.so) and, where it has
+been built, of the reference-unit libraries under oracle/_ref/.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+bench.py's cpu_baseline leg -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librrt_oracle.so")
+REF_UNITS_PATH = os.path.join(HERE, "_ref", "libref_units.so")
+REF_CAMERA_PATH = os.path.join(HERE, "_ref", "libref_camera.so")
+
+MATH_LIBM = 0
+MATH_PORTABLE = 1
+
+_f = C.c_float
+_i = C.c_int
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class Camera(C.Structure):
+    _fields_ = [("pos", _f * 3), ("forward", _f * 3), ("right", _f * 3), ("up", _f * 3)]
+
+
+class Effects(C.Structure):
+    _fields_ = [("use_bloom", C.c_int32), ("bloom_threshold", _f), ("bloom_intensity", _f),
+                ("use_vignette", C.c_int32), ("vignette_intensity", _f),
+                ("use_ca", C.c_int32), ("ca_amount", _f),
+                ("use_lens", C.c_int32), ("distortion_amount", _f)]
+
+
+class Params(C.Structure):
+    _fields_ = [("spin", _f), ("volumetrics", C.c_int32), ("max_steps", C.c_int32),
+                ("math_mode", C.c_int32), ("sky_frac_bits", C.c_int32)]
+
+
+class Diag(C.Structure):
+    _fields_ = [("steps", _ip), ("hit", _ip), ("pos", _fp), ("vel", _fp), ("rad", _fp),
+                ("n_noise", _ip), ("n_samples", _ip)]
+
+
+def build(ref=False, quiet=True):
+    """(Re)build the oracle; `ref=True` also builds oracle/_ref when /root/reference exists."""
+    targets = ["all"] + (["ref"] if ref else [])
+    subprocess.run(["make", "-C", HERE] + targets, check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.rrto_render.restype = _i
+        _lib.rrto_max_threads.restype = _i
+    return _lib
+
+
+def _fa(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(_fp)
+
+
+def default_params(**kw):
+    p = Params()
+    lib().rrto_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def default_effects(**kw):
+    e = Effects()
+    lib().rrto_default_effects(C.byref(e))
+    for k, v in kw.items():
+        setattr(e, k, v)
+    return e
+
+
+def camera(pos, forward, right, up):
+    c = Camera()
+    for name, v in (("pos", pos), ("forward", forward), ("right", right), ("up", up)):
+        arr = getattr(c, name)
+        for k in range(3):
+            arr[k] = float(v[k])
+    return c
+
+
+def max_threads():
+    return lib().rrto_max_threads()
+
+
+def render(cam, fx, prm, time, width, height, sky, rect=None, stride=(1, 1),
+           want=("rgba8",), n_threads=0):
+    """Render with the oracle.  Returns a dict of full-frame arrays (see rrt_oracle.h)."""
+    sky = np.ascontiguousarray(sky, dtype=np.uint8)
+    sh, sw = sky.shape[:2]
+    x0, y0, x1, y1 = rect if rect else (0, 0, width, height)
+    out = {}
+    rgba8 = np.zeros((height, width, 4), np.uint8) if "rgba8" in want else None
+    ldr = np.zeros((height, width, 4), np.float32) if "ldr" in want else None
+    hdr = np.zeros((height, width, 4), np.float32) if "hdr" in want else None
+    d = Diag()
+    dptr = None
+    if "diag" in want:
+        n = width * height
+        out["steps"] = np.zeros(n, np.int32); d.steps = out["steps"].ctypes.data_as(_ip)
+        out["hit"] = np.zeros(n, np.int32); d.hit = out["hit"].ctypes.data_as(_ip)
+        out["n_noise"] = np.zeros(n, np.int32); d.n_noise = out["n_noise"].ctypes.data_as(_ip)
+        out["n_samples"] = np.zeros(n, np.int32); d.n_samples = out["n_samples"].ctypes.data_as(_ip)
+        out["pos"] = np.zeros((n, 3), np.float32); d.pos = _p(out["pos"])
+        out["vel"] = np.zeros((n, 3), np.float32); d.vel = _p(out["vel"])
+        out["rad"] = np.zeros((n, 4), np.float32); d.rad = _p(out["rad"])
+        dptr = C.byref(d)
+    rc = lib().rrto_render(C.byref(cam), C.byref(fx), C.byref(prm), _f(time), width, height,
+                           x0, y0, x1, y1, stride[0], stride[1],
+                           sky.ctypes.data_as(_u8p), sw, sh,
+                           rgba8.ctypes.data_as(_u8p) if rgba8 is not None else None,
+                           _p(ldr) if ldr is not None else None,
+                           _p(hdr) if hdr is not None else None,
+                           dptr, n_threads)
+    if rc != 0:
+        raise ValueError("rrto_render: bad arguments")
+    if rgba8 is not None:
+        out["rgba8"] = rgba8
+    if ldr is not None:
+        out["ldr"] = ldr
+    if hdr is not None:
+        out["hdr"] = hdr
+    return out
+
+
+# ---------------------------------------------------------------- unit functions
+class _Units:
+    """Array-form unit functions; `prefix` is 'rrto_' (oracle) or 'ref_' (reference build)."""
+
+    def __init__(self, dll, prefix):
+        self.dll, self.pre = dll, prefix
+        self.is_ref = prefix == "ref_"
+
+    def _fn(self, name):
+        return getattr(self.dll, self.pre + name)
+
+    def hash31(self, p):
+        p = _fa(p); out = np.empty(len(p), np.float32)
+        self._fn("hash31")(len(p), _p(p), _p(out)); return out
+
+    def noise3d(self, p):
+        p = _fa(p); out = np.empty(len(p), np.float32)
+        self._fn("noise3d")(len(p), _p(p), _p(out)); return out
+
+    def fbm(self, p, octaves):
+        p = _fa(p); out = np.empty(len(p), np.float32)
+        self._fn("fbm")(len(p), _p(p), int(octaves), _p(out)); return out
+
+    def geodesic_acc(self, p, v, spin):
+        p = _fa(p); v = _fa(v); out = np.empty_like(p)
+        self._fn("geodesic_acc")(len(p), _p(p), _p(v), _f(spin), _p(out)); return out
+
+    def rk4(self, p, v, h, spin):
+        p = _fa(p).copy(); v = _fa(v).copy(); h = _fa(h)
+        self._fn("rk4")(len(p), _p(p), _p(v), _p(h), _f(spin)); return p, v
+
+    def redshift(self, p, vel, spin, mode=MATH_LIBM):
+        p = _fa(p); vel = _fa(vel); out = np.empty(len(p), np.float32)
+        if self.is_ref:
+            self._fn("redshift")(len(p), _p(p), _p(vel), _f(spin), _p(out))
+        else:
+            self._fn("redshift")(len(p), _p(p), _p(vel), _f(spin), int(mode), _p(out))
+        return out
+
+    def disk_temperature(self, r, mode=MATH_LIBM):
+        r = _fa(r); out = np.empty(len(r), np.float32)
+        if self.is_ref:
+            self._fn("disk_temperature")(len(r), _p(r), _p(out))
+        else:
+            self._fn("disk_temperature")(len(r), _p(r), int(mode), _p(out))
+        return out
+
+    def accretion_density(self, p, time, mode=MATH_LIBM):
+        p = _fa(p); out = np.empty(len(p), np.float32)
+        if self.is_ref:
+            self._fn("accretion_density")(len(p), _p(p), _f(time), _p(out))
+        else:
+            self._fn("accretion_density")(len(p), _p(p), _f(time), int(mode), _p(out))
+        return out
+
+    def dust_density(self, p, time, mode=MATH_LIBM):
+        p = _fa(p); out = np.empty(len(p), np.float32)
+        if self.is_ref:
+            self._fn("dust_density")(len(p), _p(p), _f(time), _p(out))
+        else:
+            self._fn("dust_density")(len(p), _p(p), _f(time), int(mode), _p(out))
+        return out
+
+    def smoothstep(self, e0, e1, x):
+        e0 = _fa(e0); e1 = _fa(e1); x = _fa(x); out = np.empty(len(x), np.float32)
+        self._fn("smoothstep")(len(x), _p(e0), _p(e1), _p(x), _p(out)); return out
+
+    def lens(self, uv, k):
+        uv = _fa(uv); out = np.empty_like(uv)
+        self._fn("lens")(len(uv), _p(uv), _f(k), _p(out)); return out
+
+    def vignette(self, rgb, uv, intensity):
+        rgb = _fa(rgb); uv = _fa(uv); out = np.empty_like(rgb)
+        self._fn("vignette")(len(rgb), _p(rgb), _p(uv), _f(intensity), _p(out)); return out
+
+    def bloom(self, rgb, threshold):
+        rgb = _fa(rgb); out = np.empty_like(rgb)
+        self._fn("bloom")(len(rgb), _p(rgb), _f(threshold), _p(out)); return out
+
+
+def units():
+    return _Units(lib(), "rrto_")
+
+
+def ref_available():
+    return os.path.exists(REF_UNITS_PATH)
+
+
+def ref_units():
+    """The reference's own functions (oracle/_ref); only where it has been built."""
+    return _Units(C.CDLL(REF_UNITS_PATH), "ref_")
+
+
+def ref_constants():
+    dll = C.CDLL(REF_UNITS_PATH)
+    out = np.zeros(18, np.float32)
+    dll.ref_constants(_p(out))
+    return out
+
+
+def sky_sample(dirs, off, sky, frac_bits=8, mode=MATH_LIBM):
+    dirs = _fa(dirs); sky = np.ascontiguousarray(sky, np.uint8)
+    out = np.empty((len(dirs), 4), np.float32)
+    lib().rrto_sky_sample(len(dirs), _p(dirs), _f(off), sky.ctypes.data_as(_u8p),
+                          sky.shape[1], sky.shape[0], int(frac_bits), int(mode), _p(out))
+    return out
+
+
+def math_fn(fn, mode, a, b=None):
+    """fn: 0 exp, 1 pow(a,b), 2 sin, 3 cos, 4 atan2(a,b), 5 asin."""
+    a = _fa(a); b = _fa(b if b is not None else np.zeros_like(a)); out = np.empty_like(a)
+    lib().rrto_math(int(fn), int(mode), len(a), _p(a), _p(b), _p(out))
+    return out
+
+
+class RefCamera:
+    def __init__(self):
+        self.dll = C.CDLL(REF_CAMERA_PATH)
+        self.dll.ref_lerp_angle.restype = _f
+
+    def catmull_rom(self, p0, p1, p2, p3, t):
+        a = [_fa(x) for x in (p0, p1, p2, p3)]
+        out = np.zeros(3, np.float32)
+        self.dll.ref_catmull_rom(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _f(t), _p(out))
+        return out
+
+    def lerp_angle(self, a, b, t):
+        return float(self.dll.ref_lerp_angle(_f(a), _f(b), _f(t)))
+
+    def paths(self):
+        res = []
+        for idx in range(self.dll.ref_path_count()):
+            n = self.dll.ref_path_len(idx)
+            keys = np.zeros((n, 6), np.float32)
+            self.dll.ref_path_keys(idx, _p(keys))
+            buf = C.create_string_buffer(128)
+            self.dll.ref_path_name(idx, buf, 128)
+            res.append((buf.value.decode(), keys))
+        return res

@@ -1,0 +1,614 @@
+/*
+ * rrt_oracle.c -- CPU oracle (test infrastructure; see rrt_oracle.h).
+ *
+ * Every function names the reference lines it restates.  Constants are spelled
+ * as the reference spells them (config.h values substituted into the original
+ * expressions) so that the compiler folds them exactly as it folds the
+ * reference.  Build: gcc -O2 -std=c11 -ffp-contract=off -mfma -fopenmp.
+ */
+#include "rrt_oracle.h"
+
+#include <math.h>
+#include <stddef.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../relativisticraytracer_amd/csrc/rrt_math.h"
+
+/* ---- config.h:18-48, values verbatim ---- */
+#define DISK_TEMP_REF 1.5e7f
+#define EVENT_HORIZON 2.0f
+#define ISCO_RADIUS 10.0f
+#define DISK_OUT_M 25.0f
+#define DISK_H_M 0.8f
+#define DISK_LUMINOSITY 6.0f
+#define DISK_OPACITY 0.4f
+#define EXPOSURE 0.8f
+#define CLOUD_H_M 0.5f
+#define CLOUD_OUT_M 25.0f
+#define CLOUD_OPACITY 0.3f
+#define CLOUD_LUMINOSITY 0.4f
+#define STEP_SIZE_M 0.3f
+#define PI 3.1415926535f /* math_utils.h:7 */
+
+typedef struct { float x, y, z; } f3;
+
+typedef struct {
+    int mode;        /* RRTO_MATH_* */
+    int n_noise;     /* noise3D evaluation counter (diagnostic) */
+} ctx_t;
+
+static inline float m_pow(const ctx_t* c, float x, float y) { return c->mode ? rrt_powf(x, y) : powf(x, y); }
+static inline float m_exp(const ctx_t* c, float x) { return c->mode ? rrt_expf(x) : expf(x); }
+static inline float m_sin(const ctx_t* c, float x) { return c->mode ? rrt_sinf(x) : sinf(x); }
+static inline float m_cos(const ctx_t* c, float x) { return c->mode ? rrt_cosf(x) : cosf(x); }
+static inline float m_atan2(const ctx_t* c, float y, float x) { return c->mode ? rrt_atan2f(y, x) : atan2f(y, x); }
+static inline float m_asin(const ctx_t* c, float x) { return c->mode ? rrt_asinf(x) : asinf(x); }
+
+/* ---- math_utils.h:11-48 ---- */
+static inline f3 mk3(float x, float y, float z) { f3 r = {x, y, z}; return r; }
+static inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline f3 cross3(f3 a, f3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float length3(f3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+static inline f3 normalize3(f3 v) {
+    float mag = length3(v);
+    if (mag < 1e-6f) return mk3(0, 0, 0);
+    return mk3(v.x / mag, v.y / mag, v.z / mag);
+}
+static inline f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline f3 mul3(f3 v, float s) { return mk3(v.x * s, v.y * s, v.z * s); }
+static inline float lerpf(float a, float b, float t) { return a + t * (b - a); }
+static inline float smoothstepf(float e0, float e1, float x) {
+    float t = fminf(fmaxf((x - e0) / (e1 - e0), 0.0f), 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+/* ---- math_utils.h:91-96 ---- */
+static inline float hash31(f3 p) {
+    f3 p3 = mk3(fmodf(p.x * 0.1031f, 1.0f), fmodf(p.y * 0.1031f, 1.0f), fmodf(p.z * 0.1031f, 1.0f));
+    float d = p3.x * (p3.y + 33.33f) + p3.y * (p3.z + 33.33f) + p3.z * (p3.x + 33.33f);
+    p3.x += d; p3.y += d; p3.z += d;
+    return fmodf((p3.x + p3.y) * p3.z, 1.0f);
+}
+
+/* ---- math_utils.h:98-110 ---- */
+static inline float noise3d(ctx_t* c, f3 p) {
+    c->n_noise++;
+    f3 i = mk3(floorf(p.x), floorf(p.y), floorf(p.z));
+    f3 f = mk3(p.x - i.x, p.y - i.y, p.z - i.z);
+    f3 u = mk3(f.x * f.x * (3.0f - 2.0f * f.x),
+               f.y * f.y * (3.0f - 2.0f * f.y),
+               f.z * f.z * (3.0f - 2.0f * f.z));
+    return lerpf(lerpf(lerpf(hash31(add3(i, mk3(0, 0, 0))), hash31(add3(i, mk3(1, 0, 0))), u.x),
+                       lerpf(hash31(add3(i, mk3(0, 1, 0))), hash31(add3(i, mk3(1, 1, 0))), u.x), u.y),
+                 lerpf(lerpf(hash31(add3(i, mk3(0, 0, 1))), hash31(add3(i, mk3(1, 0, 1))), u.x),
+                       lerpf(hash31(add3(i, mk3(0, 1, 1))), hash31(add3(i, mk3(1, 1, 1))), u.x), u.y), u.z);
+}
+
+/* ---- math_utils.h:112-121 ---- */
+static inline float fbm(ctx_t* c, f3 p, int octaves) {
+    float v = 0.0f;
+    float a = 0.5f;
+    for (int i = 0; i < octaves; ++i) {
+        v += a * noise3d(c, p);
+        p = mk3(p.x * 2.05f + 10.0f, p.y * 2.05f + 10.0f, p.z * 2.05f + 10.0f);
+        a *= 0.5f;
+    }
+    return v;
+}
+
+/* ---- geodesics.h:30-45; SPIN_A is the run-time `spin`, SPIN_AXIS=(0,1,0) ---- */
+static inline f3 geodesic_acc(f3 p_rel, f3 v, float spin) {
+    float r2 = dot3(p_rel, p_rel);
+    float r = sqrtf(r2);
+    if (r < EVENT_HORIZON * 0.5f) return mk3(0, 0, 0);
+
+    f3 L_vec = cross3(p_rel, v);
+    float L2 = dot3(L_vec, L_vec);
+    float radial_mag = -1.5f * EVENT_HORIZON * L2 / (r2 * r2 * r);
+    f3 radial_acc = mul3(p_rel, radial_mag);
+
+    f3 drag_dir = cross3(mk3(0, 1, 0), p_rel);
+    float drag_strength = (2.0f * spin * EVENT_HORIZON) / (r2 * r);
+    f3 dragging_acc = mul3(drag_dir, drag_strength);
+
+    return add3(radial_acc, dragging_acc);
+}
+
+/* ---- integrators.h:23-59; MASS_POS = (0,0,0) ---- */
+static inline void integrate_rk4(f3* p, f3* v, float h, float spin) {
+    const f3 MASS_POS = mk3(0.0f, 0.0f, 0.0f);
+    f3 p0 = *p;
+    f3 v0 = *v;
+
+    f3 p1 = sub3(p0, MASS_POS);
+    f3 kv1 = geodesic_acc(p1, v0, spin);
+    f3 kp1 = v0;
+
+    f3 v2 = add3(v0, mul3(kv1, h * 0.5f));
+    f3 p2_w = add3(p0, mul3(kp1, h * 0.5f));
+    f3 p2 = sub3(p2_w, MASS_POS);
+    f3 kv2 = geodesic_acc(p2, v2, spin);
+    f3 kp2 = v2;
+
+    f3 v3 = add3(v0, mul3(kv2, h * 0.5f));
+    f3 p3_w = add3(p0, mul3(kp2, h * 0.5f));
+    f3 p3 = sub3(p3_w, MASS_POS);
+    f3 kv3 = geodesic_acc(p3, v3, spin);
+    f3 kp3 = v3;
+
+    f3 v4 = add3(v0, mul3(kv3, h));
+    f3 p4_w = add3(p0, mul3(kp3, h));
+    f3 p4 = sub3(p4_w, MASS_POS);
+    f3 kv4 = geodesic_acc(p4, v4, spin);
+    f3 kp4 = v4;
+
+    f3 kv_sum = add3(kv1, add3(mul3(kv2, 2.0f), add3(mul3(kv3, 2.0f), kv4)));
+    f3 kp_sum = add3(kp1, add3(mul3(kp2, 2.0f), add3(mul3(kp3, 2.0f), kp4)));
+
+    *v = add3(*v, mul3(kv_sum, h / 6.0f));
+    *p = add3(*p, mul3(kp_sum, h / 6.0f));
+}
+
+/* ---- geodesics.h:11-25 ---- */
+static inline float redshift_factor(const ctx_t* c, f3 p_rel, f3 ray_vel, float spin) {
+    float r = length3(p_rel);
+    if (r < EVENT_HORIZON * 1.01f) return 0.0f;
+
+    float g_gravity = sqrtf(1.0f - EVENT_HORIZON / r);
+
+    float v_mag = 1.0f / (m_pow(c, r, 1.5f) + spin);
+    f3 gas_dir = normalize3(mk3(-p_rel.z, 0, p_rel.x));
+    float cos_theta = dot3(ray_vel, gas_dir);
+
+    float gamma = 1.0f / sqrtf(1.0f - v_mag * v_mag);
+    float g_doppler = 1.0f / (gamma * (1.0f - v_mag * cos_theta));
+
+    return g_gravity * g_doppler;
+}
+
+/* ---- densities.h:12-15 ---- */
+static inline float disk_temperature(const ctx_t* c, float r) {
+    if (r < ISCO_RADIUS) return 0.0f;
+    return DISK_TEMP_REF * m_pow(c, r / ISCO_RADIUS, -0.75f);
+}
+
+/* ---- densities.h:20-62 ---- */
+static inline float accretion_density(ctx_t* c, f3 p, float time) {
+    float r = length3(mk3(p.x, 0.0f, p.z));
+    if (r < ISCO_RADIUS || r > DISK_OUT_M) return 0.0f;
+
+    float edge_falloff = 1.0f;
+    float edge_start = DISK_OUT_M * 0.85f;
+    if (r > edge_start) {
+        edge_falloff = 1.0f - (r - edge_start) / (DISK_OUT_M - edge_start);
+        edge_falloff *= edge_falloff;
+    }
+
+    float local_h = DISK_H_M * m_pow(c, ISCO_RADIUS / r, 0.5f);
+    float vertical_density = m_exp(c, -(p.y * p.y) / (2.0f * local_h * local_h + 1e-7f));
+    float radial_density = m_pow(c, ISCO_RADIUS / r, 0.4f);
+    float base_envelope = vertical_density * radial_density * edge_falloff;
+
+    float phi = m_atan2(c, p.z, p.x);
+
+    float omega = 3.5f * m_pow(c, ISCO_RADIUS / r, 1.5f);
+    float angle_rotated = phi - time * omega;
+
+    f3 rot_p = mk3(r * m_cos(c, angle_rotated),
+                   p.y * 4.0f,
+                   r * m_sin(c, angle_rotated));
+
+    float evolution = time * 0.35f;
+    f3 noise_coords = add3(mul3(rot_p, 0.45f), mk3(0, evolution, 0));
+
+    float n = fbm(c, noise_coords, 5);
+
+    float cloud = fmaxf(0.0f, n - 0.32f);
+    cloud = m_pow(c, cloud * 2.8f, 1.6f);
+    cloud = fminf(6.0f, cloud);
+
+    return base_envelope * (0.02f + 5.0f * cloud);
+}
+
+/* ---- densities.h:69-132 ---- */
+static inline float dust_density(ctx_t* c, f3 p, float time) {
+    float r = length3(mk3(p.x, 0.0f, p.z));
+    if (r < ISCO_RADIUS || r > DISK_OUT_M) return 0.0f;
+
+    float edge_falloff = smoothstepf(DISK_OUT_M, DISK_OUT_M * 0.8f, r);
+    float inner_taper = smoothstepf(ISCO_RADIUS, ISCO_RADIUS + 5.0f, r);
+
+    float local_h = CLOUD_H_M * 0.5f * m_pow(c, ISCO_RADIUS / r, 0.2f);
+    float vertical_profile = m_exp(c, -(p.y * p.y) / (2.0f * local_h * local_h + 1e-7f));
+
+    float base = vertical_profile * edge_falloff * inner_taper;
+
+    if (base < 0.001f) return 0.0f;
+
+    float phi = m_atan2(c, p.z, p.x);
+    float omega = 1.0f * m_pow(c, ISCO_RADIUS / r, 1.5f);
+    float angle_rot = phi - time * omega;
+
+    f3 coords = mk3(r * 0.8f, p.y * 15.0f, angle_rot * 10.0f);
+
+    f3 w1 = mk3(fbm(c, mul3(coords, 0.15f), 2),
+                fbm(c, add3(mul3(coords, 0.15f), mk3(1, 2, 3)), 2),
+                fbm(c, add3(mul3(coords, 0.15f), mk3(4, 5, 6)), 2));
+
+    f3 w2_coords = add3(coords, mul3(w1, 3.0f));
+    f3 w2 = mk3(fbm(c, mul3(w2_coords, 0.4f), 2),
+                fbm(c, add3(mul3(w2_coords, 0.4f), mk3(2, 1, 0)), 2),
+                fbm(c, add3(mul3(w2_coords, 0.4f), mk3(0, 3, 1)), 2));
+
+    f3 final_coords = add3(coords, mul3(w2, 1.5f));
+
+    float n = 0.0f;
+    float amp = 1.0f;
+    float freq = 1.0f;
+    for (int i = 0; i < 5; i++) {
+        float noise_val = noise3d(c, mul3(final_coords, freq));
+        float wisp = 1.0f - fabsf(noise_val * 2.0f - 1.0f);
+        n += wisp * amp;
+        amp *= 0.5f;
+        freq *= 2.1f;
+    }
+
+    float strands = smoothstepf(0.4f, 0.8f, n * 0.55f);
+    strands = m_pow(c, strands, 4.0f);
+
+    float detail = fbm(c, add3(mul3(final_coords, 4.0f), mk3(0, time * 0.5f, 0)), 2);
+    strands *= (0.6f + 0.4f * detail);
+
+    return base * strands * 12.0f;
+}
+
+/* ---- post_processing.h:13-31 ---- */
+static inline f3 apply_vignette(f3 color, float uvx, float uvy, float intensity) {
+    float d = length3(sub3(mk3(uvx, uvy, 0), mk3(0.5f, 0.5f, 0)));
+    float v = smoothstepf(0.8f, 0.2f, d * intensity);
+    return mul3(color, v);
+}
+static inline void apply_lens_distortion(float* uvx, float* uvy, float k) {
+    float tx = *uvx - 0.5f, ty = *uvy - 0.5f;
+    float r2 = tx * tx + ty * ty;
+    float f = 1.0f + r2 * k;
+    *uvx = tx * f + 0.5f;
+    *uvy = ty * f + 0.5f;
+}
+static inline f3 bloom_contribution(f3 color, float threshold) {
+    float brightness = dot3(color, mk3(0.2126f, 0.7152f, 0.0722f));
+    if (brightness > threshold) return color;
+    return mk3(0, 0, 0);
+}
+
+/*
+ * Sky lookup.  The reference samples a CUDA texture object (main.cpp:255-261:
+ * wrap in x, clamp in y, linear filter, normalized coords, texel/255 reads).
+ * The hardware filter has no definition in the reference source; this is the
+ * build's definition, following the bilinear rule the CUDA programming guide
+ * documents (xB = x - 0.5, weights from frac(xB) kept to `frac_bits`
+ * fractional bits).  PARITY UNPINNED for this function.
+ */
+static inline int wrapi(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+static inline int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
+static inline void sky_fetch(const uint8_t* sky, int sw, int sh, int frac_bits,
+                             float tx, float ty, float out[4]) {
+    float xb = tx * (float)sw - 0.5f;
+    float yb = ty * (float)sh - 0.5f;
+    float fi = floorf(xb), fj = floorf(yb);
+    float a = xb - fi, b = yb - fj;
+    if (frac_bits > 0) {
+        float q = (float)(1 << frac_bits);
+        a = floorf(a * q + 0.5f) / q;
+        b = floorf(b * q + 0.5f) / q;
+    }
+    int i0 = wrapi((int)fi, sw), i1 = wrapi((int)fi + 1, sw);
+    int j0 = clampi((int)fj, 0, sh - 1), j1 = clampi((int)fj + 1, 0, sh - 1);
+    float w00 = (1.0f - a) * (1.0f - b);
+    float w10 = a * (1.0f - b);
+    float w01 = (1.0f - a) * b;
+    float w11 = a * b;
+    const uint8_t* t00 = sky + 4 * ((size_t)j0 * sw + i0);
+    const uint8_t* t10 = sky + 4 * ((size_t)j0 * sw + i1);
+    const uint8_t* t01 = sky + 4 * ((size_t)j1 * sw + i0);
+    const uint8_t* t11 = sky + 4 * ((size_t)j1 * sw + i1);
+    for (int ch = 0; ch < 4; ++ch) {
+        out[ch] = w00 * ((float)t00[ch] / 255.0f) + w10 * ((float)t10[ch] / 255.0f)
+                + w01 * ((float)t01[ch] / 255.0f) + w11 * ((float)t11[ch] / 255.0f);
+    }
+}
+
+/* raymarcher.cu:134-140 */
+static inline void sample_sky(const ctx_t* c, f3 dir, float off, const uint8_t* sky, int sw, int sh,
+                              int frac_bits, float out[4]) {
+    float phi = m_atan2(c, dir.z, dir.x) + off;
+    float theta = m_asin(c, dir.y);
+    float tx = 0.5f + phi / (2.0f * PI);
+    float ty = 0.5f - theta / PI;
+    sky_fetch(sky, sw, sh, frac_bits, tx, ty, out);
+}
+
+/* ---- raymarcher.cu:15-174, one pixel ---- */
+typedef struct {
+    uint8_t rgba[4];
+    float ldr[3];
+    float hdr[3];
+    int steps, hit, n_noise, n_samples;
+    f3 p, v;
+    float rad[4];
+} pixel_out;
+
+static void trace_pixel(const rrto_camera* cam, const rrto_effects* fx, const rrto_params* prm,
+                        float time, int width, int height, int x, int y,
+                        const uint8_t* sky, int sw, int sh, pixel_out* o) {
+    ctx_t c = {prm->math_mode, 0};
+    const float spin = prm->spin;
+
+    float uvx = (float)x / width;
+    float uvy = (float)y / height;
+
+    if (fx->use_lens) apply_lens_distortion(&uvx, &uvy, fx->distortion_amount);
+
+    float u_coord = uvx * 2.0f - 1.0f;
+    float v_coord = uvy * 2.0f - 1.0f;
+    float aspect = (float)width / height;
+    u_coord *= aspect;
+
+    f3 cpos = mk3(cam->pos[0], cam->pos[1], cam->pos[2]);
+    f3 cfwd = mk3(cam->forward[0], cam->forward[1], cam->forward[2]);
+    f3 crgt = mk3(cam->right[0], cam->right[1], cam->right[2]);
+    f3 cup = mk3(cam->up[0], cam->up[1], cam->up[2]);
+
+    f3 p = cpos;
+    f3 rd = normalize3(add3(cfwd, add3(mul3(crgt, u_coord), mul3(cup, v_coord))));
+    f3 vel = rd;
+
+    float intensity_r = 0, intensity_g = 0, intensity_b = 0;
+    float transmittance = 1.0f;
+    int hit_horizon = 0;
+    int n_samples = 0;
+    const f3 MASS_POS = mk3(0.0f, 0.0f, 0.0f);
+
+    int i;
+    for (i = 0; i < prm->max_steps; i++) {
+        f3 rel_p = sub3(p, MASS_POS);
+        float r2 = dot3(rel_p, rel_p);
+        float r = sqrtf(r2);
+
+        if (r < EVENT_HORIZON * 1.01f) {
+            hit_horizon = 1;
+            transmittance = 0.0f;
+            break;
+        }
+
+        float current_h = STEP_SIZE_M;
+        int near_bh = (r < 18.0f);
+        int in_disk_zone = (fabsf(rel_p.y) < DISK_H_M * 5.0f && r < DISK_OUT_M + 5.0f);
+        int in_cloud_zone = (fabsf(rel_p.y) < CLOUD_H_M * 1.5f && r < CLOUD_OUT_M);
+
+        if (near_bh) current_h *= 0.1f;
+        else if (in_disk_zone) current_h *= 0.3f;
+        else if (in_cloud_zone) current_h *= 0.5f;
+
+        integrate_rk4(&p, &vel, current_h, spin);
+
+        if (in_disk_zone || in_cloud_zone) {
+            /* volumetrics == 0 is the build's "skybox only" switch (BASELINE.json configs[1]):
+               both densities read as 0, the zone-dependent step sizes stay. */
+            float d_disk = (in_disk_zone && prm->volumetrics) ? accretion_density(&c, rel_p, time) : 0.0f;
+            float d_cloud = (in_cloud_zone && prm->volumetrics) ? dust_density(&c, rel_p, time) : 0.0f;
+
+            if (d_disk > 0.001f || d_cloud > 0.001f) {
+                f3 step_emit = mk3(0, 0, 0);
+                float step_opacity = 0;
+                n_samples++;
+
+                if (d_disk > 0.001f) {
+                    float g = redshift_factor(&c, rel_p, vel, spin);
+                    float T = disk_temperature(&c, r);
+                    float T_norm = m_pow(&c, T / DISK_TEMP_REF, 0.5f);
+                    float bol_I = m_pow(&c, g, 4.0f) * T_norm * d_disk * DISK_LUMINOSITY;
+
+                    float color_t = g * m_pow(&c, T / DISK_TEMP_REF, 0.4f) * 2.5f;
+                    step_emit.x += 1.0f * bol_I;
+                    step_emit.y += fminf(0.25f, 0.12f * color_t) * bol_I;
+                    step_emit.z += fmaxf(0.0f, 0.01f * (color_t - 2.0f)) * bol_I;
+
+                    step_opacity += d_disk * DISK_OPACITY;
+                }
+
+                if (d_cloud > 0.001f) {
+                    float g = redshift_factor(&c, rel_p, vel, spin);
+                    float lighting = 0.5f + 3.0f * m_pow(&c, ISCO_RADIUS / fmaxf(r, ISCO_RADIUS), 1.2f);
+                    float cloud_I = d_cloud * CLOUD_LUMINOSITY * lighting;
+
+                    float shift = smoothstepf(0.7f, 1.3f, g);
+                    f3 base_color = mk3(0.60f, 0.65f, 0.80f);
+
+                    step_emit.x += base_color.x * cloud_I * lerpf(1.2f, 0.8f, shift);
+                    step_emit.y += base_color.y * cloud_I * lerpf(0.8f, 1.1f, shift);
+                    step_emit.z += base_color.z * cloud_I * lerpf(0.6f, 1.4f, shift);
+
+                    step_opacity += d_cloud * CLOUD_OPACITY;
+                }
+
+                float d_tau = step_opacity * current_h;
+                float step_trans = m_exp(&c, -d_tau);
+                float factor = (1.0f - step_trans) * transmittance;
+
+                intensity_r += step_emit.x * factor;
+                intensity_g += step_emit.y * factor;
+                intensity_b += step_emit.z * factor;
+
+                transmittance *= step_trans;
+            }
+        }
+
+        if (r > 250.0f && dot3(rel_p, vel) > 0) { i++; break; }
+    }
+    /* `i` = number of RK4 steps taken */
+
+    f3 bg_color = mk3(0, 0, 0);
+    if (!hit_horizon) {
+        f3 d = normalize3(vel);
+        float offset = fx->use_ca ? fx->ca_amount : 0.0f;
+        float sR[4], sG[4], sB[4];
+        sample_sky(&c, d, offset, sky, sw, sh, prm->sky_frac_bits, sR);
+        sample_sky(&c, d, 0.0f, sky, sw, sh, prm->sky_frac_bits, sG);
+        sample_sky(&c, d, -offset, sky, sw, sh, prm->sky_frac_bits, sB);
+        bg_color = mk3(sR[0], sG[1], sB[2]);
+    }
+
+    f3 final_hdr;
+    final_hdr.x = intensity_r + bg_color.x * transmittance;
+    final_hdr.y = intensity_g + bg_color.y * transmittance;
+    final_hdr.z = intensity_b + bg_color.z * transmittance;
+
+    if (fx->use_bloom) {
+        f3 bloom = bloom_contribution(final_hdr, fx->bloom_threshold);
+        final_hdr = add3(final_hdr, mul3(bloom, fx->bloom_intensity));
+    }
+    if (fx->use_vignette) {
+        final_hdr = apply_vignette(final_hdr, uvx, uvy, fx->vignette_intensity);
+    }
+
+    float out_r = 1.0f - m_exp(&c, -final_hdr.x * EXPOSURE);
+    float out_g = 1.0f - m_exp(&c, -final_hdr.y * EXPOSURE);
+    float out_b = 1.0f - m_exp(&c, -final_hdr.z * EXPOSURE);
+
+    o->rgba[0] = (unsigned char)(out_r * 255);
+    o->rgba[1] = (unsigned char)(out_g * 255);
+    o->rgba[2] = (unsigned char)(out_b * 255);
+    o->rgba[3] = 255;
+    o->ldr[0] = out_r; o->ldr[1] = out_g; o->ldr[2] = out_b;
+    o->hdr[0] = final_hdr.x; o->hdr[1] = final_hdr.y; o->hdr[2] = final_hdr.z;
+    o->steps = i;
+    o->hit = hit_horizon;
+    o->n_noise = c.n_noise;
+    o->n_samples = n_samples;
+    o->p = p; o->v = vel;
+    o->rad[0] = intensity_r; o->rad[1] = intensity_g; o->rad[2] = intensity_b; o->rad[3] = transmittance;
+}
+
+int rrto_render(const rrto_camera* cam, const rrto_effects* fx, const rrto_params* prm,
+                float time, int width, int height,
+                int x0, int y0, int x1, int y1, int sx, int sy,
+                const uint8_t* sky, int sw, int sh,
+                uint8_t* rgba8, float* ldr, float* hdr, const rrto_diag* diag, int n_threads) {
+    if (!cam || !fx || !prm || !sky || width <= 0 || height <= 0 || sw <= 0 || sh <= 0) return -1;
+    if (x0 < 0 || y0 < 0 || x1 > width || y1 > height || sx <= 0 || sy <= 0) return -1;
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    (void)n_threads;
+#endif
+    int ny = (y1 - y0 + sy - 1) / sy;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int jy = 0; jy < ny; ++jy) {
+        int y = y0 + jy * sy;
+        for (int x = x0; x < x1; x += sx) {
+            pixel_out o;
+            trace_pixel(cam, fx, prm, time, width, height, x, y, sky, sw, sh, &o);
+            size_t oi = (size_t)(height - 1 - y) * width + x;   /* raymarcher.cu:168 */
+            size_t di = (size_t)y * width + x;
+            if (rgba8) memcpy(rgba8 + 4 * oi, o.rgba, 4);
+            if (ldr) { ldr[4 * oi] = o.ldr[0]; ldr[4 * oi + 1] = o.ldr[1]; ldr[4 * oi + 2] = o.ldr[2]; ldr[4 * oi + 3] = 1.0f; }
+            if (hdr) { hdr[4 * oi] = o.hdr[0]; hdr[4 * oi + 1] = o.hdr[1]; hdr[4 * oi + 2] = o.hdr[2]; hdr[4 * oi + 3] = 1.0f; }
+            if (diag) {
+                if (diag->steps) diag->steps[di] = o.steps;
+                if (diag->hit) diag->hit[di] = o.hit;
+                if (diag->n_noise) diag->n_noise[di] = o.n_noise;
+                if (diag->n_samples) diag->n_samples[di] = o.n_samples;
+                if (diag->pos) { diag->pos[3 * di] = o.p.x; diag->pos[3 * di + 1] = o.p.y; diag->pos[3 * di + 2] = o.p.z; }
+                if (diag->vel) { diag->vel[3 * di] = o.v.x; diag->vel[3 * di + 1] = o.v.y; diag->vel[3 * di + 2] = o.v.z; }
+                if (diag->rad) memcpy(diag->rad + 4 * di, o.rad, 16);
+            }
+        }
+    }
+    return 0;
+}
+
+int rrto_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void rrto_default_params(rrto_params* p) {
+    p->spin = 0.0f;            /* config.h:21 */
+    p->volumetrics = 1;
+    p->max_steps = 2000;       /* config.h:48 */
+    p->math_mode = RRTO_MATH_LIBM;
+    p->sky_frac_bits = 8;
+}
+
+void rrto_default_effects(rrto_effects* e) {   /* camera_settings.h:5-16 */
+    e->use_bloom = 1; e->bloom_threshold = 0.8f; e->bloom_intensity = 0.5f;
+    e->use_vignette = 1; e->vignette_intensity = 0.4f;
+    e->use_ca = 0; e->ca_amount = 0.005f;
+    e->use_lens = 1; e->distortion_amount = 0.15f;
+}
+
+/* ---- array wrappers for unit tests ---- */
+static inline f3 ld3(const float* a, int i) { return mk3(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
+static inline void st3(float* a, int i, f3 v) { a[3 * i] = v.x; a[3 * i + 1] = v.y; a[3 * i + 2] = v.z; }
+
+void rrto_hash31(int n, const float* p, float* out) { for (int i = 0; i < n; ++i) out[i] = hash31(ld3(p, i)); }
+void rrto_noise3d(int n, const float* p, float* out) { ctx_t c = {0, 0}; for (int i = 0; i < n; ++i) out[i] = noise3d(&c, ld3(p, i)); }
+void rrto_fbm(int n, const float* p, int oct, float* out) { ctx_t c = {0, 0}; for (int i = 0; i < n; ++i) out[i] = fbm(&c, ld3(p, i), oct); }
+void rrto_geodesic_acc(int n, const float* p, const float* v, float spin, float* out) {
+    for (int i = 0; i < n; ++i) st3(out, i, geodesic_acc(ld3(p, i), ld3(v, i), spin));
+}
+void rrto_rk4(int n, float* p, float* v, const float* h, float spin) {
+    for (int i = 0; i < n; ++i) { f3 pp = ld3(p, i), vv = ld3(v, i); integrate_rk4(&pp, &vv, h[i], spin); st3(p, i, pp); st3(v, i, vv); }
+}
+void rrto_redshift(int n, const float* p, const float* vel, float spin, int mode, float* out) {
+    ctx_t c = {mode, 0}; for (int i = 0; i < n; ++i) out[i] = redshift_factor(&c, ld3(p, i), ld3(vel, i), spin);
+}
+void rrto_disk_temperature(int n, const float* r, int mode, float* out) {
+    ctx_t c = {mode, 0}; for (int i = 0; i < n; ++i) out[i] = disk_temperature(&c, r[i]);
+}
+void rrto_accretion_density(int n, const float* p, float time, int mode, float* out) {
+    ctx_t c = {mode, 0}; for (int i = 0; i < n; ++i) out[i] = accretion_density(&c, ld3(p, i), time);
+}
+void rrto_dust_density(int n, const float* p, float time, int mode, float* out) {
+    ctx_t c = {mode, 0}; for (int i = 0; i < n; ++i) out[i] = dust_density(&c, ld3(p, i), time);
+}
+void rrto_smoothstep(int n, const float* e0, const float* e1, const float* x, float* out) {
+    for (int i = 0; i < n; ++i) out[i] = smoothstepf(e0[i], e1[i], x[i]);
+}
+void rrto_lens(int n, const float* uv, float k, float* out) {
+    for (int i = 0; i < n; ++i) { float a = uv[2 * i], b = uv[2 * i + 1]; apply_lens_distortion(&a, &b, k); out[2 * i] = a; out[2 * i + 1] = b; }
+}
+void rrto_vignette(int n, const float* rgb, const float* uv, float intensity, float* out) {
+    for (int i = 0; i < n; ++i) st3(out, i, apply_vignette(ld3(rgb, i), uv[2 * i], uv[2 * i + 1], intensity));
+}
+void rrto_bloom(int n, const float* rgb, float threshold, float* out) {
+    for (int i = 0; i < n; ++i) st3(out, i, bloom_contribution(ld3(rgb, i), threshold));
+}
+void rrto_sky_sample(int n, const float* dir, float off, const uint8_t* sky, int sw, int sh,
+                     int frac_bits, int mode, float* out) {
+    ctx_t c = {mode, 0}; for (int i = 0; i < n; ++i) sample_sky(&c, ld3(dir, i), off, sky, sw, sh, frac_bits, out + 4 * i);
+}
+void rrto_math(int fn, int mode, int n, const float* a, const float* b, float* out) {
+    ctx_t c = {mode, 0};
+    for (int i = 0; i < n; ++i) {
+        switch (fn) {
+            case 0: out[i] = m_exp(&c, a[i]); break;
+            case 1: out[i] = m_pow(&c, a[i], b[i]); break;
+            case 2: out[i] = m_sin(&c, a[i]); break;
+            case 3: out[i] = m_cos(&c, a[i]); break;
+            case 4: out[i] = m_atan2(&c, a[i], b[i]); break;
+            case 5: out[i] = m_asin(&c, a[i]); break;
+            default: out[i] = 0.0f;
+        }
+    }
+}

@@ -1,0 +1,207 @@
+"""relativisticraytracer_amd -- MI355X (gfx950) implementation of the per-pixel
+geodesic ray-march hot path of levi2234/RelativisticRayTracer.
+
+Host-side mirror of the reference's interface for this path
+(include/raymarcher.h:11-19, include/camera_effects/camera_settings.h:4-17):
+
+    cam = rrt.CameraState.from_angles((0, 10, -60), yaw=0, pitch=-10)
+    sky = rrt.SkyTexture(rgba8_numpy)
+    out = torch.empty(h * w * 4, dtype=torch.uint8, device="cuda")
+    rrt.launch_raymarch(out, w, h, time, cam, sky, rrt.CameraEffects())
+
+Everything goes through the C ABI of librrt_hip.so (include/rrt.h).  torch is
+only used for device memory / streams and is optional: any object with a
+`data_ptr()` or a plain integer device address is accepted.  There is no CPU
+implementation in this package.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import RRTError, rrt_camera, rrt_debug_outputs, rrt_effects, rrt_params  # noqa: F401
+
+__all__ = ["CameraState", "CameraEffects", "RenderParams", "SkyTexture", "launch_raymarch",
+           "launch_raymarch_rows", "launch_raymarch_tiles", "assemble_tiles", "tile_shard_rows",
+           "launch_raymarch_debug", "RRTError", "device_count", "abi_version"]
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    raise TypeError(f"expected a device tensor or an integer device address, got {type(x)}")
+
+
+def _stream(stream):
+    if stream is None:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        except Exception:
+            pass
+        return None
+    if isinstance(stream, int):
+        return C.c_void_p(stream)
+    return C.c_void_p(stream.cuda_stream)
+
+
+class CameraState(rrt_camera):
+    """Reference `struct CameraState` (include/raymarcher.h:11-16)."""
+
+    def __init__(self, pos=(0, 0, 0), forward=(0, 0, 1), right=(1, 0, 0), up=(0, 1, 0)):
+        super().__init__()
+        for name, v in (("pos", pos), ("forward", forward), ("right", right), ("up", up)):
+            arr = getattr(self, name)
+            for k in range(3):
+                arr[k] = float(v[k])
+
+    @classmethod
+    def from_angles(cls, pos, yaw, pitch):
+        """CameraController::getCUDAStateFrom (src/main.cpp:141-167); degrees."""
+        out = cls()
+        p = (C.c_float * 3)(*[float(v) for v in pos])
+        _lib.check(_lib.load().rrt_camera_from_angles(C.byref(p), float(yaw), float(pitch), C.byref(out)),
+                   "rrt_camera_from_angles")
+        return out
+
+    @classmethod
+    def default(cls):
+        """The reference's start-up camera (src/main.cpp:128-130)."""
+        return cls.from_angles((0.0, 10.0, -60.0), 0.0, -10.0)
+
+    def as_array(self):
+        return np.array([list(self.pos), list(self.forward), list(self.right), list(self.up)], np.float32)
+
+
+class CameraEffects(rrt_effects):
+    """Reference `struct CameraEffects` with its default member initialisers
+    (camera_settings.h:5-16); attribute names follow the reference."""
+
+    _ALIASES = {"useBloom": "use_bloom", "bloomThreshold": "bloom_threshold",
+                "bloomIntensity": "bloom_intensity", "useVignette": "use_vignette",
+                "vignetteIntensity": "vignette_intensity",
+                "useChromaticAberration": "use_chromatic_aberration", "caAmount": "ca_amount",
+                "useLensDistortion": "use_lens_distortion", "distortionAmount": "distortion_amount"}
+
+    def __init__(self, **kw):
+        super().__init__()
+        _lib.check(_lib.load().rrt_effects_default(C.byref(self)), "rrt_effects_default")
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def __setattr__(self, k, v):
+        k = self._ALIASES.get(k, k)
+        if k.startswith("use_"):
+            v = 1 if v else 0
+        super().__setattr__(k, v)
+
+    def __getattr__(self, k):
+        alias = type(self)._ALIASES.get(k)
+        if alias is None:
+            raise AttributeError(k)
+        return getattr(self, alias)
+
+
+class RenderParams(rrt_params):
+    """Scene constants of include/config.h as run-time parameters (defaults == config.h)."""
+
+    def __init__(self, **kw):
+        super().__init__()
+        _lib.check(_lib.load().rrt_params_default(C.byref(self)), "rrt_params_default")
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError(k)
+            setattr(self, k, v)
+
+
+class SkyTexture:
+    """Device-resident RGBA8 equirectangular sky; stands in for the reference's
+    cudaTextureObject_t (src/main.cpp:237-266)."""
+
+    def __init__(self, rgba8):
+        arr = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        if arr.ndim != 3 or arr.shape[2] != 4:
+            raise ValueError("sky must be an (H, W, 4) uint8 array")
+        self.height, self.width = arr.shape[:2]
+        h = C.c_ulonglong(0)
+        _lib.check(_lib.load().rrt_sky_create(arr.ctypes.data_as(C.c_void_p), self.width, self.height,
+                                              C.byref(h)), "rrt_sky_create")
+        self.handle = h.value
+
+    def destroy(self):
+        if getattr(self, "handle", 0):
+            _lib.load().rrt_sky_destroy(self.handle)
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def _sky_handle(sky):
+    return sky.handle if isinstance(sky, SkyTexture) else int(sky)
+
+
+def abi_version():
+    return _lib.load().rrt_abi_version()
+
+
+def device_count():
+    n = C.c_int(0)
+    _lib.load().rrt_device_count(C.byref(n))
+    return n.value
+
+
+def launch_raymarch(d_out, w, h, time, cam, skyboxTex, effects, params=None, stream=None):
+    """Drop-in for the reference's launch_raymarch (include/raymarcher.h:19): asynchronous,
+    writes w*h RGBA8 pixels (bottom-up rows, alpha 255) to the device buffer `d_out`."""
+    _lib.check(_lib.load().rrt_launch_raymarch(_ptr(d_out), w, h, float(time), C.byref(cam),
+                                               _sky_handle(skyboxTex), C.byref(effects),
+                                               C.byref(params) if params is not None else None,
+                                               _stream(stream)), "rrt_launch_raymarch")
+
+
+def launch_raymarch_rows(d_out_rows, w, h, y0, y1, time, cam, skyboxTex, effects, params=None, stream=None):
+    _lib.check(_lib.load().rrt_launch_raymarch_rows(_ptr(d_out_rows), w, h, y0, y1, float(time), C.byref(cam),
+                                                    _sky_handle(skyboxTex), C.byref(effects),
+                                                    C.byref(params) if params is not None else None,
+                                                    _stream(stream)), "rrt_launch_raymarch_rows")
+
+
+def launch_raymarch_tiles(d_out_tiles, w, h, tile_rows, shard, n_shards, time, cam, skyboxTex, effects,
+                          params=None, stream=None):
+    _lib.check(_lib.load().rrt_launch_raymarch_tiles(_ptr(d_out_tiles), w, h, tile_rows, shard, n_shards,
+                                                     float(time), C.byref(cam), _sky_handle(skyboxTex),
+                                                     C.byref(effects),
+                                                     C.byref(params) if params is not None else None,
+                                                     _stream(stream)), "rrt_launch_raymarch_tiles")
+
+
+def tile_shard_rows(h, tile_rows, shard, n_shards):
+    rows = C.c_int(0)
+    _lib.check(_lib.load().rrt_tile_shard_rows(h, tile_rows, shard, n_shards, C.byref(rows)),
+               "rrt_tile_shard_rows")
+    return rows.value
+
+
+def assemble_tiles(d_frame, d_tiles, w, h, tile_rows, shard, n_shards, stream=None):
+    _lib.check(_lib.load().rrt_assemble_tiles(_ptr(d_frame), _ptr(d_tiles), w, h, tile_rows, shard, n_shards,
+                                              _stream(stream)), "rrt_assemble_tiles")
+
+
+def launch_raymarch_debug(d_out, w, h, time, cam, skyboxTex, effects, params=None, stream=None, **outs):
+    """Full-frame launch that also fills per-ray outputs: ldr, hdr, steps, hit, pos, vel, rad."""
+    dbg = rrt_debug_outputs()
+    for k, v in outs.items():
+        setattr(dbg, "d_" + k, _ptr(v).value if v is not None else None)
+    _lib.check(_lib.load().rrt_launch_raymarch_ex(_ptr(d_out), w, h, float(time), C.byref(cam),
+                                                  _sky_handle(skyboxTex), C.byref(effects),
+                                                  C.byref(params) if params is not None else None,
+                                                  C.byref(dbg), _stream(stream)), "rrt_launch_raymarch_ex")

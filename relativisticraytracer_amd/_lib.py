@@ -1,0 +1,113 @@
+"""ctypes loader for librrt_hip.so (C ABI: include/rrt.h).
+
+There is deliberately no CPU fallback: if the HIP library is missing or a
+launch fails, the call raises.
+"""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "librrt_hip.so")
+
+RRT_OK = 0
+
+
+class RRTError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__(f"{where}: {detail}" if detail else where)
+
+
+class rrt_camera(C.Structure):
+    """== reference struct CameraState, include/raymarcher.h:11-16 (48 bytes)."""
+    _fields_ = [("pos", C.c_float * 3), ("forward", C.c_float * 3),
+                ("right", C.c_float * 3), ("up", C.c_float * 3)]
+
+
+class rrt_effects(C.Structure):
+    """== reference struct CameraEffects, camera_settings.h:4-17 (36 bytes)."""
+    _fields_ = [("use_bloom", C.c_uint8), ("_pad0", C.c_uint8 * 3),
+                ("bloom_threshold", C.c_float), ("bloom_intensity", C.c_float),
+                ("use_vignette", C.c_uint8), ("_pad1", C.c_uint8 * 3),
+                ("vignette_intensity", C.c_float),
+                ("use_chromatic_aberration", C.c_uint8), ("_pad2", C.c_uint8 * 3),
+                ("ca_amount", C.c_float),
+                ("use_lens_distortion", C.c_uint8), ("_pad3", C.c_uint8 * 3),
+                ("distortion_amount", C.c_float)]
+
+
+class rrt_params(C.Structure):
+    _fields_ = [("spin", C.c_float), ("max_steps", C.c_int32), ("volumetrics", C.c_int32),
+                ("sky_frac_bits", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class rrt_debug_outputs(C.Structure):
+    _fields_ = [("d_ldr", C.c_void_p), ("d_hdr", C.c_void_p), ("d_steps", C.c_void_p),
+                ("d_hit", C.c_void_p), ("d_pos", C.c_void_p), ("d_vel", C.c_void_p),
+                ("d_rad", C.c_void_p)]
+
+
+# every symbol include/rrt.h declares: (name, restype, argtypes)
+_vp, _i, _f, _ull = C.c_void_p, C.c_int, C.c_float, C.c_ulonglong
+_cam, _fx, _prm = C.POINTER(rrt_camera), C.POINTER(rrt_effects), C.POINTER(rrt_params)
+SYMBOLS = [
+    ("rrt_abi_version", _i, []),
+    ("rrt_status_string", C.c_char_p, [_i]),
+    ("rrt_last_hip_error", C.c_char_p, []),
+    ("rrt_device_count", _i, [C.POINTER(_i)]),
+    ("rrt_params_default", _i, [_prm]),
+    ("rrt_effects_default", _i, [_fx]),
+    ("rrt_sky_create", _i, [_vp, _i, _i, C.POINTER(_ull)]),
+    ("rrt_sky_create_from_device", _i, [_vp, _i, _i, C.POINTER(_ull)]),
+    ("rrt_sky_destroy", _i, [_ull]),
+    ("rrt_launch_raymarch", _i, [_vp, _i, _i, _f, _cam, _ull, _fx, _prm, _vp]),
+    ("rrt_launch_raymarch_rows", _i, [_vp, _i, _i, _i, _i, _f, _cam, _ull, _fx, _prm, _vp]),
+    ("rrt_launch_raymarch_tiles", _i, [_vp, _i, _i, _i, _i, _i, _f, _cam, _ull, _fx, _prm, _vp]),
+    ("rrt_tile_shard_rows", _i, [_i, _i, _i, _i, C.POINTER(_i)]),
+    ("rrt_assemble_tiles", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    ("rrt_launch_raymarch_ex", _i, [_vp, _i, _i, _f, _cam, _ull, _fx, _prm,
+                                    C.POINTER(rrt_debug_outputs), _vp]),
+    ("rrt_unit_geodesic_acc", _i, [_i, _vp, _vp, _f, _vp, _vp]),
+    ("rrt_unit_rk4", _i, [_i, _vp, _vp, _vp, _f, _vp]),
+    ("rrt_unit_hash31", _i, [_i, _vp, _vp, _vp]),
+    ("rrt_unit_noise3d", _i, [_i, _vp, _vp, _vp]),
+    ("rrt_unit_fbm", _i, [_i, _vp, _i, _vp, _vp]),
+    ("rrt_unit_accretion_density", _i, [_i, _vp, _f, _vp, _vp]),
+    ("rrt_unit_dust_density", _i, [_i, _vp, _f, _vp, _vp]),
+    ("rrt_unit_redshift", _i, [_i, _vp, _vp, _f, _vp, _vp]),
+    ("rrt_unit_math", _i, [_i, _i, _vp, _vp, _vp, _vp]),
+    ("rrt_unit_sky_sample", _i, [_i, _vp, _f, _ull, _i, _vp, _vp]),
+    ("rrt_camera_from_angles", _i, [C.POINTER(C.c_float * 3), _f, _f, _cam]),
+]
+
+_lib = None
+
+
+def load():
+    """Load librrt_hip.so.  Raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RRTError(-1, "librrt_hip.so is missing",
+                       f"expected {LIB_PATH}; run `python -m relativisticraytracer_amd.build`")
+    try:  # share torch's HIP runtime when torch is in the process (same SONAME libamdhip64.so.7)
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, where):
+    if status != RRT_OK:
+        lib = load()
+        msg = lib.rrt_status_string(status).decode()
+        if status == 3:
+            msg += " -- " + lib.rrt_last_hip_error().decode()
+        raise RRTError(status, where, msg)

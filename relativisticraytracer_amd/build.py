@@ -1,0 +1,56 @@
+"""Build librrt_hip.so (the gfx950 kernels + C ABI) in-tree with hipcc.
+
+    python -m relativisticraytracer_amd.build [--force] [--save-temps]
+
+The library is cross-compiled (no GPU needed) and lands in
+relativisticraytracer_amd/lib/, from where the ctypes loader picks it up and
+from where it travels to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "librrt_hip.so")
+SOURCES = [os.path.join(CSRC, "rrt_hip.hip")]
+HEADERS = [os.path.join(CSRC, "rrt_device.h"), os.path.join(CSRC, "rrt_math.h"),
+           os.path.join(PKG, "..", "include", "rrt.h")]
+
+# -ffp-contract=off: the kernels' arithmetic contract (csrc/rrt_device.h).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc_path():
+    p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(p):
+        raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+    return p
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS + [os.path.abspath(__file__)])
+
+
+def build_lib(force=False, extra_flags=(), verbose=False):
+    if not force and not is_stale():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + SOURCES + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=LIBDIR)
+    return LIB
+
+
+if __name__ == "__main__":
+    extra = []
+    if "--save-temps" in sys.argv:
+        extra += ["-save-temps", "-Rpass-analysis=kernel-resource-usage"]
+    print(build_lib(force="--force" in sys.argv or bool(extra), extra_flags=extra, verbose=True))

@@ -1,0 +1,592 @@
+/*
+ * rrt_hip.hip -- gfx950 kernels and the C ABI (include/rrt.h) of librrt_hip.so.
+ *
+ * Replaces the reference's only CUDA translation unit, src/raymarcher.cu
+ * (raymarch_kernel :15-174 and launch_raymarch :176-180).  Built with
+ *   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+ * (relativisticraytracer_amd/build.py).  gfx950 only: no other target, no
+ * CUDA dual path.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "../../include/rrt.h"
+#include "rrt_device.h"
+
+namespace {
+
+using namespace rrt;
+
+thread_local char g_hip_err[256] = "";
+
+int hip_fail(hipError_t e, const char* what) {
+    snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, hipGetErrorString(e));
+    return RRT_ERR_HIP;
+}
+#define RRT_HIP(call)                                       \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);   \
+    } while (0)
+
+/* ------------------------------------------------------------------ sky handles */
+struct SkyObject {
+    uint32_t magic;
+    uint8_t* d_texels;
+    int w, h;
+    bool owned;
+};
+constexpr uint32_t kSkyMagic = 0x52525453u; /* "RRTS" */
+
+SkyObject* sky_from_handle(rrt_sky_t h) {
+    SkyObject* s = reinterpret_cast<SkyObject*>(static_cast<uintptr_t>(h));
+    if (!s || s->magic != kSkyMagic) return nullptr;
+    return s;
+}
+
+/* ------------------------------------------------------------------ kernel arguments */
+struct RowMap {        /* local row -> image row, and where its pixels go */
+    int n_local_rows;  /* rows rendered by this launch                               */
+    int y_base;        /* first image row of tile 0 of shard 0                        */
+    int tile_rows;     /* R                                                           */
+    int shard;         /* s                                                           */
+    int n_shards;      /* G: local tile k is image tile s + k*G                       */
+};
+
+struct FrameArgs {
+    uchar4* out;
+    int width, height;
+    float time;
+    rrt_camera cam;
+    SkyTex sky;
+    /* effects (camera_settings.h) */
+    int use_bloom, use_vignette, use_ca, use_lens;
+    float bloom_threshold, bloom_intensity, vignette_intensity, ca_amount, distortion_amount;
+    /* params */
+    float spin, drag_c;
+    int max_steps;
+    RowMap rows;
+    rrt_debug_outputs dbg;
+};
+
+/* image row of local row `lr`, and the local output row it is stored at */
+__device__ __forceinline__ bool map_row(const RowMap& m, int height, int lr, int& y, int& out_row) {
+    if (lr >= m.n_local_rows) return false;
+    int k = lr / m.tile_rows;
+    int rr = lr - k * m.tile_rows;
+    int t = m.shard + k * m.n_shards;
+    int ty0 = m.y_base + t * m.tile_rows;
+    y = ty0 + rr;
+    if (y >= height) return false;
+    int rows_k = min(m.tile_rows, height - ty0);
+    out_row = k * m.tile_rows + (rows_k - 1 - rr);     /* each tile bottom-up, raymarcher.cu:168 */
+    return true;
+}
+
+/*
+ * Per-pixel pipeline, one ray per lane (reference raymarch_kernel,
+ * src/raymarcher.cu:15-174).  A 256-thread workgroup covers a 16x16 pixel
+ * block as four 8x8 wave tiles so that the 64 rays of a wavefront stay
+ * spatially coherent (similar step counts, similar zone entry).
+ */
+template <bool SPIN, bool VOL, bool DEBUG>
+__global__ __launch_bounds__(256) void raymarch_pixels(const FrameArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int lr = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    int y, out_row;
+    if (x >= a.width || !map_row(a.rows, a.height, lr, y, out_row)) return;
+
+    /* raymarcher.cu:20-34 */
+    float uvx = (float)x / (float)a.width;
+    float uvy = (float)y / (float)a.height;
+    if (a.use_lens) {                                   /* post_processing.h:19-24 */
+        float tx = uvx - 0.5f, ty = uvy - 0.5f;
+        float r2 = tx * tx + ty * ty;
+        float f = 1.0f + r2 * a.distortion_amount;
+        uvx = tx * f + 0.5f;
+        uvy = ty * f + 0.5f;
+    }
+    float u_coord = uvx * 2.0f - 1.0f;
+    float v_coord = uvy * 2.0f - 1.0f;
+    float aspect = (float)a.width / (float)a.height;
+    u_coord *= aspect;
+
+    const v3 cfw = mk(a.cam.forward[0], a.cam.forward[1], a.cam.forward[2]);
+    const v3 crt = mk(a.cam.right[0], a.cam.right[1], a.cam.right[2]);
+    const v3 cup = mk(a.cam.up[0], a.cam.up[1], a.cam.up[2]);
+    v3 p = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
+    v3 vel = normalize(add(cfw, add(mul(crt, u_coord), mul(cup, v_coord))));
+
+    Radiance acc = {0.f, 0.f, 0.f, 1.0f};
+    bool hit = false;
+    int i = 0;
+
+    /* raymarcher.cu:41-121 */
+    for (; i < a.max_steps; ++i) {
+        const v3 rel_p = p;                             /* p - MASS_POS, MASS_POS = 0 */
+        const float r2 = dot(rel_p, rel_p);
+        const float r = sqrtf(r2);
+        if (r < kEventHorizon * 1.01f) { hit = true; acc.t = 0.0f; break; }
+
+        float h = kStepSize;
+        const bool near_bh = r < 18.0f;
+        const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
+        const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
+        if (near_bh) h *= 0.1f;
+        else if (in_disk) h *= 0.3f;
+        else if (in_cloud) h *= 0.5f;
+
+        integrate_rk4<SPIN>(p, vel, h, a.drag_c);
+
+        if (VOL && (in_disk || in_cloud)) {
+            float d_disk = in_disk ? accretion_density<true>(rel_p, a.time) : 0.0f;
+            float d_cloud = in_cloud ? dust_density(rel_p, a.time) : 0.0f;
+            accumulate_sample(acc, d_disk, d_cloud, rel_p, r, vel, h, a.spin);
+        }
+        if (r > 250.0f && dot(rel_p, vel) > 0.0f) { ++i; break; }
+    }
+
+    /* raymarcher.cu:124-150 */
+    float bg_r = 0.f, bg_g = 0.f, bg_b = 0.f;
+    if (!hit) {
+        v3 d = normalize(vel);
+        float s[4];
+        if (a.use_ca) {
+            sample_sky(a.sky, d, a.ca_amount, s);  bg_r = s[0];
+            sample_sky(a.sky, d, 0.0f, s);         bg_g = s[1];
+            sample_sky(a.sky, d, -a.ca_amount, s); bg_b = s[2];
+        } else {                                   /* offset 0: the three lookups coincide */
+            sample_sky(a.sky, d, 0.0f, s);
+            bg_r = s[0]; bg_g = s[1]; bg_b = s[2];
+        }
+    }
+    float hx = acc.r + bg_r * acc.t;
+    float hy = acc.g + bg_g * acc.t;
+    float hz = acc.b + bg_b * acc.t;
+
+    /* raymarcher.cu:154-161, post_processing.h:13-31 */
+    if (a.use_bloom) {
+        float brightness = hx * 0.2126f + hy * 0.7152f + hz * 0.0722f;
+        bool on = brightness > a.bloom_threshold;
+        float bx = on ? hx : 0.f, by = on ? hy : 0.f, bz = on ? hz : 0.f;
+        hx = hx + bx * a.bloom_intensity;
+        hy = hy + by * a.bloom_intensity;
+        hz = hz + bz * a.bloom_intensity;
+    }
+    if (a.use_vignette) {
+        float dx = uvx - 0.5f, dy = uvy - 0.5f;
+        float dd = sqrtf(dx * dx + dy * dy + 0.0f * 0.0f);
+        float vg = smoothstep(0.8f, 0.2f, dd * a.vignette_intensity);
+        hx *= vg; hy *= vg; hz *= vg;
+    }
+
+    /* raymarcher.cu:164-173 */
+    float out_r = 1.0f - rrt_expf(-hx * kExposure);
+    float out_g = 1.0f - rrt_expf(-hy * kExposure);
+    float out_b = 1.0f - rrt_expf(-hz * kExposure);
+    const size_t oi = (size_t)out_row * a.width + x;
+    a.out[oi] = make_uchar4((unsigned char)(int)(out_r * 255.0f), (unsigned char)(int)(out_g * 255.0f),
+                            (unsigned char)(int)(out_b * 255.0f), 255);
+    if (DEBUG) {
+        const size_t di = (size_t)y * a.width + x;
+        if (a.dbg.d_ldr) { float* q = a.dbg.d_ldr + 4 * oi; q[0] = out_r; q[1] = out_g; q[2] = out_b; q[3] = 1.0f; }
+        if (a.dbg.d_hdr) { float* q = a.dbg.d_hdr + 4 * oi; q[0] = hx; q[1] = hy; q[2] = hz; q[3] = 1.0f; }
+        if (a.dbg.d_steps) a.dbg.d_steps[di] = i;
+        if (a.dbg.d_hit) a.dbg.d_hit[di] = hit ? 1 : 0;
+        if (a.dbg.d_pos) { float* q = a.dbg.d_pos + 3 * di; q[0] = p.x; q[1] = p.y; q[2] = p.z; }
+        if (a.dbg.d_vel) { float* q = a.dbg.d_vel + 3 * di; q[0] = vel.x; q[1] = vel.y; q[2] = vel.z; }
+        if (a.dbg.d_rad) { float* q = a.dbg.d_rad + 4 * di; q[0] = acc.r; q[1] = acc.g; q[2] = acc.b; q[3] = acc.t; }
+    }
+}
+
+/* scatter one shard's tile buffer into the full bottom-up frame */
+__global__ __launch_bounds__(256) void assemble_tiles_kernel(uchar4* frame, const uchar4* tiles, int width,
+                                                            int height, RowMap m) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int lr = blockIdx.y;
+    int y, out_row;
+    if (x >= width || !map_row(m, height, lr, y, out_row)) return;
+    frame[(size_t)(height - 1 - y) * width + x] = tiles[(size_t)out_row * width + x];
+}
+
+/* ------------------------------------------------------------------ unit kernels */
+__device__ __forceinline__ v3 ld3(const float* a, int i) { return mk(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
+__device__ __forceinline__ void st3(float* a, int i, v3 v) { a[3 * i] = v.x; a[3 * i + 1] = v.y; a[3 * i + 2] = v.z; }
+
+__global__ void k_geodesic_acc(int n, const float* p, const float* v, float spin, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float drag_c = (2.0f * spin) * 2.0f;
+    st3(out, i, geodesic_acc<true>(ld3(p, i), ld3(v, i), drag_c));
+}
+__global__ void k_rk4(int n, float* p, float* v, const float* h, float spin) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    v3 pp = ld3(p, i), vv = ld3(v, i);
+    float drag_c = (2.0f * spin) * 2.0f;
+    if (spin != 0.0f) integrate_rk4<true>(pp, vv, h[i], drag_c);
+    else integrate_rk4<false>(pp, vv, h[i], drag_c);
+    st3(p, i, pp); st3(v, i, vv);
+}
+__global__ void k_hash31(int n, const float* p, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = hash31(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+}
+__global__ void k_noise3d(int n, const float* p, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = noise3d(ld3(p, i));
+}
+__global__ void k_fbm(int n, const float* p, int oct, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    v3 q = ld3(p, i);
+    float v = 0.0f, amp = 0.5f;
+    for (int o = 0; o < oct; ++o) {
+        v += amp * noise3d(q);
+        q = mk(q.x * 2.05f + 10.0f, q.y * 2.05f + 10.0f, q.z * 2.05f + 10.0f);
+        amp *= 0.5f;
+    }
+    out[i] = v;
+}
+__global__ void k_accretion(int n, const float* p, float time, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = accretion_density<false>(ld3(p, i), time);
+}
+__global__ void k_dust(int n, const float* p, float time, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = dust_density(ld3(p, i), time);
+}
+__global__ void k_redshift(int n, const float* p, const float* vel, float spin, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = redshift_factor(ld3(p, i), ld3(vel, i), spin);
+}
+__global__ void k_math(int fn, int n, const float* a, const float* b, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 0.0f;
+    switch (fn) {
+        case 0: r = rrt_expf(a[i]); break;
+        case 1: r = rrt_powf(a[i], b[i]); break;
+        case 2: r = rrt_sinf(a[i]); break;
+        case 3: r = rrt_cosf(a[i]); break;
+        case 4: r = rrt_atan2f(a[i], b[i]); break;
+        case 5: r = rrt_asinf(a[i]); break;
+        default: break;
+    }
+    out[i] = r;
+}
+__global__ void k_sky(int n, const float* dir, float off, SkyTex sky, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s[4];
+    sample_sky(sky, ld3(dir, i), off, s);
+    out[4 * i] = s[0]; out[4 * i + 1] = s[1]; out[4 * i + 2] = s[2]; out[4 * i + 3] = s[3];
+}
+
+/* ------------------------------------------------------------------ host helpers */
+int check_common(const void* out, int width, int height, const rrt_camera* cam, const rrt_effects* fx,
+                 const rrt_params* prm) {
+    if (!out || !cam || !fx || width <= 0 || height <= 0) return RRT_ERR_INVALID_ARGUMENT;
+    if ((long long)width * height > (1ll << 31) - 1) return RRT_ERR_INVALID_ARGUMENT;
+    if (prm) {
+        if (prm->max_steps < 0 || prm->sky_frac_bits < 0 || prm->sky_frac_bits > 16) return RRT_ERR_INVALID_ARGUMENT;
+        if (!(prm->spin == prm->spin)) return RRT_ERR_INVALID_ARGUMENT;
+        for (int k = 0; k < 4; ++k)
+            if (prm->reserved[k] != 0) return RRT_ERR_INVALID_ARGUMENT;
+    }
+    return RRT_OK;
+}
+
+int fill_args(FrameArgs& a, bool& vol, void* out, int width, int height, float time, const rrt_camera* cam,
+              rrt_sky_t sky, const rrt_effects* fx, const rrt_params* prm_in) {
+    rrt_params prm;
+    if (prm_in) prm = *prm_in; else rrt_params_default(&prm);
+    SkyObject* s = sky_from_handle(sky);
+    if (!s) return RRT_ERR_BAD_HANDLE;
+    a.out = static_cast<uchar4*>(out);
+    a.width = width; a.height = height; a.time = time; a.cam = *cam;
+    a.sky.texels = s->d_texels; a.sky.w = s->w; a.sky.h = s->h; a.sky.frac_bits = prm.sky_frac_bits;
+    a.use_bloom = fx->use_bloom != 0; a.use_vignette = fx->use_vignette != 0;
+    a.use_ca = fx->use_chromatic_aberration != 0; a.use_lens = fx->use_lens_distortion != 0;
+    a.bloom_threshold = fx->bloom_threshold; a.bloom_intensity = fx->bloom_intensity;
+    a.vignette_intensity = fx->vignette_intensity; a.ca_amount = fx->ca_amount;
+    a.distortion_amount = fx->distortion_amount;
+    a.spin = prm.spin;
+    a.drag_c = (2.0f * prm.spin) * 2.0f;            /* 2.0f * SPIN_A * EVENT_HORIZON, geodesics.h:41 */
+    a.max_steps = prm.max_steps;
+    memset(&a.dbg, 0, sizeof(a.dbg));
+    vol = prm.volumetrics != 0;
+    return RRT_OK;
+}
+
+int launch(const FrameArgs& a, bool vol, bool debug, hipStream_t st) {
+    dim3 block(256);
+    dim3 grid((a.width + 15) / 16, (a.rows.n_local_rows + 15) / 16);
+    if (grid.y == 0) return RRT_OK;
+    const bool spin = a.spin != 0.0f;
+#define RRT_LAUNCH(S, V, D) hipLaunchKernelGGL((raymarch_pixels<S, V, D>), grid, block, 0, st, a)
+    if (debug) {
+        if (spin) { if (vol) RRT_LAUNCH(true, true, true); else RRT_LAUNCH(true, false, true); }
+        else      { if (vol) RRT_LAUNCH(false, true, true); else RRT_LAUNCH(false, false, true); }
+    } else {
+        if (spin) { if (vol) RRT_LAUNCH(true, true, false); else RRT_LAUNCH(true, false, false); }
+        else      { if (vol) RRT_LAUNCH(false, true, false); else RRT_LAUNCH(false, false, false); }
+    }
+#undef RRT_LAUNCH
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+
+int shard_rows(int height, int tile_rows, int shard, int n_shards) {
+    int n_tiles = (height + tile_rows - 1) / tile_rows;
+    int rows = 0;
+    for (int t = shard; t < n_tiles; t += n_shards) rows += (t * tile_rows + tile_rows <= height) ? tile_rows : (height - t * tile_rows);
+    return rows;
+}
+
+template <class F>
+int unit_launch(int n, void* stream, F f) {
+    if (n < 0) return RRT_ERR_INVALID_ARGUMENT;
+    if (n == 0) return RRT_OK;
+    f(dim3((n + 255) / 256), dim3(256), static_cast<hipStream_t>(stream));
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+
+}  // namespace
+
+/* ====================================================================== C ABI */
+extern "C" {
+
+int rrt_abi_version(void) { return RRT_ABI_VERSION; }
+
+const char* rrt_status_string(int s) {
+    switch (s) {
+        case RRT_OK: return "ok";
+        case RRT_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case RRT_ERR_NO_DEVICE: return "no HIP device";
+        case RRT_ERR_HIP: return "HIP runtime error";
+        case RRT_ERR_BAD_HANDLE: return "bad sky handle";
+        case RRT_ERR_OUT_OF_MEMORY: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+const char* rrt_last_hip_error(void) { return g_hip_err; }
+
+int rrt_device_count(int* count) {
+    if (!count) return RRT_ERR_INVALID_ARGUMENT;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); return RRT_ERR_NO_DEVICE; }
+    *count = n;
+    return n > 0 ? RRT_OK : RRT_ERR_NO_DEVICE;
+}
+
+int rrt_params_default(rrt_params* p) {
+    if (!p) return RRT_ERR_INVALID_ARGUMENT;
+    memset(p, 0, sizeof(*p));
+    p->spin = 0.0f;          /* SPIN_A    config.h:21 */
+    p->max_steps = 2000;     /* MAX_STEPS config.h:48 */
+    p->volumetrics = 1;
+    p->sky_frac_bits = 8;
+    return RRT_OK;
+}
+
+int rrt_effects_default(rrt_effects* e) {    /* camera_settings.h:5-16 */
+    if (!e) return RRT_ERR_INVALID_ARGUMENT;
+    memset(e, 0, sizeof(*e));
+    e->use_bloom = 1; e->bloom_threshold = 0.8f; e->bloom_intensity = 0.5f;
+    e->use_vignette = 1; e->vignette_intensity = 0.4f;
+    e->use_chromatic_aberration = 0; e->ca_amount = 0.005f;
+    e->use_lens_distortion = 1; e->distortion_amount = 0.15f;
+    return RRT_OK;
+}
+
+int rrt_sky_create(const uint8_t* rgba8_host, int width, int height, rrt_sky_t* out) {
+    if (!rgba8_host || !out || width <= 0 || height <= 0) return RRT_ERR_INVALID_ARGUMENT;
+    SkyObject* s = new (std::nothrow) SkyObject;
+    if (!s) return RRT_ERR_OUT_OF_MEMORY;
+    size_t bytes = (size_t)width * height * 4;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_texels), bytes);
+    if (e != hipSuccess) { delete s; return hip_fail(e, "hipMalloc(sky)"); }
+    e = hipMemcpy(s->d_texels, rgba8_host, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(s->d_texels); delete s; return hip_fail(e, "hipMemcpy(sky)"); }
+    s->magic = kSkyMagic; s->w = width; s->h = height; s->owned = true;
+    *out = static_cast<rrt_sky_t>(reinterpret_cast<uintptr_t>(s));
+    return RRT_OK;
+}
+
+int rrt_sky_create_from_device(const void* d_rgba8, int width, int height, rrt_sky_t* out) {
+    if (!d_rgba8 || !out || width <= 0 || height <= 0) return RRT_ERR_INVALID_ARGUMENT;
+    SkyObject* s = new (std::nothrow) SkyObject;
+    if (!s) return RRT_ERR_OUT_OF_MEMORY;
+    s->magic = kSkyMagic; s->d_texels = const_cast<uint8_t*>(static_cast<const uint8_t*>(d_rgba8));
+    s->w = width; s->h = height; s->owned = false;
+    *out = static_cast<rrt_sky_t>(reinterpret_cast<uintptr_t>(s));
+    return RRT_OK;
+}
+
+int rrt_sky_destroy(rrt_sky_t sky) {
+    SkyObject* s = sky_from_handle(sky);
+    if (!s) return RRT_ERR_BAD_HANDLE;
+    int rc = RRT_OK;
+    if (s->owned) {
+        hipError_t e = hipFree(s->d_texels);
+        if (e != hipSuccess) rc = hip_fail(e, "hipFree(sky)");
+    }
+    s->magic = 0;
+    delete s;
+    return rc;
+}
+
+int rrt_launch_raymarch_rows(void* d_out_rows, int width, int height, int y0, int y1, float time,
+                             const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx,
+                             const rrt_params* prm, void* stream) {
+    int rc = check_common(d_out_rows, width, height, cam, fx, prm);
+    if (rc) return rc;
+    if (y0 < 0 || y1 > height || y0 > y1) return RRT_ERR_INVALID_ARGUMENT;
+    FrameArgs a;
+    bool vol;
+    rc = fill_args(a, vol, d_out_rows, width, height, time, cam, sky, fx, prm);
+    if (rc) return rc;
+    a.rows = RowMap{y1 - y0, y0, y1 - y0 > 0 ? y1 - y0 : 1, 0, 1};
+    return launch(a, vol, false, static_cast<hipStream_t>(stream));
+}
+
+int rrt_launch_raymarch(void* d_out_rgba8, int width, int height, float time, const rrt_camera* cam,
+                        rrt_sky_t sky, const rrt_effects* fx, const rrt_params* prm, void* stream) {
+    return rrt_launch_raymarch_rows(d_out_rgba8, width, height, 0, height, time, cam, sky, fx, prm, stream);
+}
+
+int rrt_launch_raymarch_ex(void* d_out_rgba8, int width, int height, float time, const rrt_camera* cam,
+                           rrt_sky_t sky, const rrt_effects* fx, const rrt_params* prm,
+                           const rrt_debug_outputs* dbg, void* stream) {
+    int rc = check_common(d_out_rgba8, width, height, cam, fx, prm);
+    if (rc) return rc;
+    FrameArgs a;
+    bool vol;
+    rc = fill_args(a, vol, d_out_rgba8, width, height, time, cam, sky, fx, prm);
+    if (rc) return rc;
+    a.rows = RowMap{height, 0, height, 0, 1};
+    if (dbg) a.dbg = *dbg;
+    return launch(a, vol, dbg != nullptr, static_cast<hipStream_t>(stream));
+}
+
+int rrt_tile_shard_rows(int height, int tile_rows, int shard, int n_shards, int* rows) {
+    if (!rows || height <= 0 || tile_rows <= 0 || n_shards <= 0 || shard < 0 || shard >= n_shards)
+        return RRT_ERR_INVALID_ARGUMENT;
+    *rows = shard_rows(height, tile_rows, shard, n_shards);
+    return RRT_OK;
+}
+
+int rrt_launch_raymarch_tiles(void* d_out_tiles, int width, int height, int tile_rows, int shard, int n_shards,
+                              float time, const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx,
+                              const rrt_params* prm, void* stream) {
+    int rc = check_common(d_out_tiles, width, height, cam, fx, prm);
+    if (rc) return rc;
+    if (tile_rows <= 0 || n_shards <= 0 || shard < 0 || shard >= n_shards) return RRT_ERR_INVALID_ARGUMENT;
+    FrameArgs a;
+    bool vol;
+    rc = fill_args(a, vol, d_out_tiles, width, height, time, cam, sky, fx, prm);
+    if (rc) return rc;
+    a.rows = RowMap{shard_rows(height, tile_rows, shard, n_shards), 0, tile_rows, shard, n_shards};
+    return launch(a, vol, false, static_cast<hipStream_t>(stream));
+}
+
+int rrt_assemble_tiles(void* d_frame, const void* d_tiles, int width, int height, int tile_rows, int shard,
+                       int n_shards, void* stream) {
+    if (!d_frame || !d_tiles || width <= 0 || height <= 0 || tile_rows <= 0 || n_shards <= 0 || shard < 0 ||
+        shard >= n_shards)
+        return RRT_ERR_INVALID_ARGUMENT;
+    RowMap m{shard_rows(height, tile_rows, shard, n_shards), 0, tile_rows, shard, n_shards};
+    if (m.n_local_rows == 0) return RRT_OK;
+    dim3 grid((width + 255) / 256, m.n_local_rows);
+    hipLaunchKernelGGL(assemble_tiles_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<uchar4*>(d_frame), static_cast<const uchar4*>(d_tiles), width, height, m);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+
+/* ---- unit kernels ---- */
+int rrt_unit_geodesic_acc(int n, const float* p, const float* v, float spin, float* out, void* st) {
+    if (n > 0 && (!p || !v || !out)) return RRT_ERR_INVALID_ARGUMENT;
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_geodesic_acc, g, b, 0, s, n, p, v, spin, out); });
+}
+int rrt_unit_rk4(int n, float* p, float* v, const float* h, float spin, void* st) {
+    if (n > 0 && (!p || !v || !h)) return RRT_ERR_INVALID_ARGUMENT;
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_rk4, g, b, 0, s, n, p, v, h, spin); });
+}
+int rrt_unit_hash31(int n, const float* p, float* out, void* st) {
+    if (n > 0 && (!p || !out)) return RRT_ERR_INVALID_ARGUMENT;
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_hash31, g, b, 0, s, n, p, out); });
+}
+int rrt_unit_noise3d(int n, const float* p, float* out, void* st) {
+    if (n > 0 && (!p || !out)) return RRT_ERR_INVALID_ARGUMENT;
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_noise3d, g, b, 0, s, n, p, out); });
+}
+int rrt_unit_fbm(int n, const float* p, int oct, float* out, void* st) {
+    if (n > 0 && (!p || !out)) return RRT_ERR_INVALID_ARGUMENT;
+    if (oct < 0 || oct > 16) return RRT_ERR_INVALID_ARGUMENT;
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_fbm, g, b, 0, s, n, p, oct, out); });
+}
+int rrt_unit_accretion_density(int n, const float* p, float time, float* out, void* st) {
+    if (n > 0 && (!p || !out)) return RRT_ERR_INVALID_ARGUMENT;
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_accretion, g, b, 0, s, n, p, time, out); });
+}
+int rrt_unit_dust_density(int n, const float* p, float time, float* out, void* st) {
+    if (n > 0 && (!p || !out)) return RRT_ERR_INVALID_ARGUMENT;
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_dust, g, b, 0, s, n, p, time, out); });
+}
+int rrt_unit_redshift(int n, const float* p, const float* vel, float spin, float* out, void* st) {
+    if (n > 0 && (!p || !vel || !out)) return RRT_ERR_INVALID_ARGUMENT;
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_redshift, g, b, 0, s, n, p, vel, spin, out); });
+}
+int rrt_unit_math(int fn, int n, const float* a, const float* b, float* out, void* st) {
+    if (n > 0 && (!a || !b || !out)) return RRT_ERR_INVALID_ARGUMENT;
+    if (fn < 0 || fn > 5) return RRT_ERR_INVALID_ARGUMENT;
+    return unit_launch(n, st, [&](dim3 g, dim3 bl, hipStream_t s) { hipLaunchKernelGGL(k_math, g, bl, 0, s, fn, n, a, b, out); });
+}
+int rrt_unit_sky_sample(int n, const float* dir, float off, rrt_sky_t sky, int frac_bits, float* out, void* st) {
+    if (n > 0 && (!dir || !out)) return RRT_ERR_INVALID_ARGUMENT;
+    if (frac_bits < 0 || frac_bits > 16) return RRT_ERR_INVALID_ARGUMENT;
+    SkyObject* so = sky_from_handle(sky);
+    if (!so) return RRT_ERR_BAD_HANDLE;
+    SkyTex t{so->d_texels, so->w, so->h, frac_bits};
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_sky, g, b, 0, s, n, dir, off, t, out); });
+}
+
+/* CameraController::getCUDAStateFrom, reference src/main.cpp:141-167 (host C++ there too).
+ * Note the reference's 3.14159f, not PI. */
+int rrt_camera_from_angles(const float pos[3], float yaw, float pitch, rrt_camera* out) {
+    if (!pos || !out) return RRT_ERR_INVALID_ARGUMENT;
+    float radYaw = yaw * 3.14159f / 180.0f;
+    float radPitch = pitch * 3.14159f / 180.0f;
+    float fx = std::sin(radYaw) * std::cos(radPitch);
+    float fy = std::sin(radPitch);
+    float fz = std::cos(radYaw) * std::cos(radPitch);
+    float mag = std::sqrt(fx * fx + fy * fy + fz * fz);
+    fx /= mag; fy /= mag; fz /= mag;
+    const float ux = 0.0f, uy = 1.0f, uz = 0.0f;
+    float rx = uy * fz - uz * fy;
+    float ry = uz * fx - ux * fz;
+    float rz = ux * fy - uy * fx;
+    float rMag = std::sqrt(rx * rx + ry * ry + rz * rz);
+    rx /= rMag; ry /= rMag; rz /= rMag;
+    float upx = fy * rz - fz * ry;
+    float upy = fz * rx - fx * rz;
+    float upz = fx * ry - fy * rx;
+    out->pos[0] = pos[0]; out->pos[1] = pos[1]; out->pos[2] = pos[2];
+    out->forward[0] = fx; out->forward[1] = fy; out->forward[2] = fz;
+    out->right[0] = rx; out->right[1] = ry; out->right[2] = rz;
+    out->up[0] = upx; out->up[1] = upy; out->up[2] = upz;
+    return RRT_OK;
+}
+
+}  // extern "C"

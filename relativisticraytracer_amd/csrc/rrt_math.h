@@ -1,0 +1,216 @@
+/*
+ * rrt_math.h -- portable, bit-reproducible single-precision transcendentals.
+ *
+ * Why this exists
+ * ---------------
+ * The reference hot path (/root/reference/src/raymarcher.cu:15-174 and the
+ * headers it pulls in) calls powf / expf / sinf / cosf / atan2f / asinf from
+ * CUDA libdevice.  Those implementations cannot be reproduced here (no CUDA),
+ * glibc's differ from ROCm OCML's by an ulp here and there, and the path has
+ * hard gates (`d > 0.001f`, raymarcher.cu:71,76,91; `base < 0.001f`,
+ * densities.h:85) that turn 1-ulp differences into visible LSB flips.
+ *
+ * So the product defines ONE implementation of the six functions, written in
+ * plain IEEE binary32 `+ - * /`, `sqrtf` and *explicit* `fmaf` only (no
+ * compiler contraction: every translation unit that includes this header is
+ * built with -ffp-contract=off).  The same source is compiled
+ *   - by hipcc into the gfx950 kernels (v_fma_f32 is exact fused), and
+ *   - by gcc into the CPU oracle's "portable" mode (vfmadd / libm fmaf, exact),
+ * which makes the HIP output byte-identical to the oracle.  The oracle's
+ * default mode keeps glibc libm so the two can be compared (tests/).
+ *
+ * Accuracy target: <= 4 ulp on the argument ranges the path produces, i.e. the
+ * error class CUDA documents for its own single-precision library.  Measured
+ * against glibc in tests/test_portable_math.py.
+ *
+ * Algorithms: argument reductions and minimax polynomials follow the published
+ * Cephes single-precision library (S. Moshier); powf is exp(y*log x) with the
+ * logarithm carried as an unevaluated hi+lo pair.
+ */
+#ifndef RRT_MATH_H
+#define RRT_MATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RRT_FN __host__ __device__ static __forceinline__
+#else
+#define RRT_FN static inline __attribute__((always_inline))
+#endif
+
+RRT_FN uint32_t rrt_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+RRT_FN float rrt_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+RRT_FN float rrt_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+RRT_FN float rrt_sqrt(float x) { return __builtin_sqrtf(x); }
+RRT_FN float rrt_abs(float x) { return __builtin_fabsf(x); }
+
+#define RRT_LN2_HI 0.693359375f        /* 10 significant bits: k*LN2_HI is exact */
+#define RRT_LN2_LO (-2.12194440e-4f)   /* ln2 = LN2_HI + LN2_LO */
+#define RRT_LOG2E 1.44269504088896341f
+#define RRT_RND_MAGIC 12582912.0f      /* 1.5 * 2^23: x + M - M == rint(x) */
+
+/* 2^k for k in [-126, 127] */
+RRT_FN float rrt_pow2i(int k) { return rrt_u2f((uint32_t)(k + 127) << 23); }
+
+/* exp(hi + lo) for |lo| << |hi|; shared tail of expf and powf. */
+RRT_FN float rrt_exp_hl(float hi, float lo) {
+    if (hi > 88.7228394f) return rrt_u2f(0x7f800000u);
+    if (hi < -104.0f) return 0.0f;
+    float t = rrt_fma(hi, RRT_LOG2E, RRT_RND_MAGIC);
+    float k = t - RRT_RND_MAGIC;
+    float r = rrt_fma(k, -RRT_LN2_HI, hi);
+    r = rrt_fma(k, -RRT_LN2_LO, r);
+    r = r + lo;
+    float z = r * r;
+    float p = 1.9875691500E-4f;
+    p = rrt_fma(p, r, 1.3981999507E-3f);
+    p = rrt_fma(p, r, 8.3334519073E-3f);
+    p = rrt_fma(p, r, 4.1665795894E-2f);
+    p = rrt_fma(p, r, 1.6666665459E-1f);
+    p = rrt_fma(p, r, 5.0000001201E-1f);
+    float y = rrt_fma(p, z, r) + 1.0f;
+    int ki = (int)k;
+    int k1 = ki >> 1;
+    int k2 = ki - k1;
+    return (y * rrt_pow2i(k1)) * rrt_pow2i(k2);
+}
+
+RRT_FN float rrt_expf(float x) {
+    if (x != x) return x;
+    return rrt_exp_hl(x, 0.0f);
+}
+
+/* x^y for finite x > 0 via exp(y*log(x)), log carried as hi+lo. */
+RRT_FN float rrt_pow_pos(float x, float y) {
+    int e0 = 0;
+    uint32_t ix = rrt_f2u(x);
+    if (ix < 0x00800000u) { x = x * 16777216.0f; e0 = -24; ix = rrt_f2u(x); }
+    uint32_t adj = ix - 0x3f3504f3u;                 /* m in [sqrt(1/2), sqrt(2)) */
+    int e = ((int32_t)adj >> 23) + e0;
+    float m = rrt_u2f((adj & 0x007fffffu) + 0x3f3504f3u);
+    float f = m - 1.0f;                              /* exact */
+    float t = 2.0f + f;
+    float t_lo = (2.0f - t) + f;                     /* exact rounding error of t */
+    float rt = 1.0f / t;
+    float s = f * rt;
+    float res = rrt_fma(-s, t, f);
+    res = rrt_fma(-s, t_lo, res);
+    float s_lo = res * rt;
+    float z = s * s;
+    /* log(m) = 2 atanh(s) = 2s + s*z*(2/3 + 2/5 z + 2/7 z^2 + 2/9 z^3 + 2/11 z^4) */
+    float q = rrt_fma(z, 0.181818187f, 0.222222224f);
+    q = rrt_fma(q, z, 0.285714298f);
+    q = rrt_fma(q, z, 0.400000006f);
+    q = rrt_fma(q, z, 0.666666687f);
+    float R = (s * z) * q;
+    float hi = 2.0f * s;
+    float lo = rrt_fma(2.0f, s_lo, R);
+    float ef = (float)e;
+    float a = ef * RRT_LN2_HI;                       /* exact */
+    float L_hi = a + hi;                             /* TwoSum */
+    float bb = L_hi - a;
+    float err = (a - (L_hi - bb)) + (hi - bb);
+    float L_lo = err + lo;
+    L_lo = rrt_fma(ef, RRT_LN2_LO, L_lo);
+    float P_hi = y * L_hi;
+    float P_lo = rrt_fma(y, L_hi, -P_hi);
+    P_lo = rrt_fma(y, L_lo, P_lo);
+    return rrt_exp_hl(P_hi, P_lo);
+}
+
+/*
+ * powf as the path uses it: base >= 0, finite, and the exponent is one of a
+ * handful of literals (geodesics.h:17, densities.h:14,32,34,41,58,80,89,125,
+ * raymarcher.cu:79,80,82,93).  Exponents with an exact radical form are
+ * evaluated through sqrt/multiplies (<= 2 ulp, usually correctly rounded);
+ * everything else goes through rrt_pow_pos.  Negative bases do not occur.
+ */
+RRT_FN float rrt_powf(float x, float y) {
+    if (x != x) return x;
+    if (x == 0.0f) return (y > 0.0f) ? 0.0f : ((y == 0.0f) ? 1.0f : rrt_u2f(0x7f800000u));
+    if (x == rrt_u2f(0x7f800000u)) return (y > 0.0f) ? x : ((y == 0.0f) ? 1.0f : 0.0f);
+    if (y == 0.5f) return rrt_sqrt(x);
+    if (y == 1.5f) return x * rrt_sqrt(x);
+    if (y == 4.0f) { float x2 = x * x; return x2 * x2; }
+    return rrt_pow_pos(x, y);
+}
+
+/* sin and cos of x together (|x| < ~8000 for full accuracy). */
+RRT_FN void rrt_sincosf(float x, float* sn, float* cs) {
+    float ax = rrt_abs(x);
+    int j = (int)(ax * 1.27323954473516f);           /* 4/pi */
+    j = (j + 1) & ~1;
+    float y = (float)j;
+    float r = rrt_fma(y, -0.78515625f, ax);
+    r = rrt_fma(y, -2.4187564849853515625e-4f, r);
+    r = rrt_fma(y, -3.77489497744594108e-8f, r);
+    float z = r * r;
+    float ps = -1.9515295891E-4f;
+    ps = rrt_fma(ps, z, 8.3321608736E-3f);
+    ps = rrt_fma(ps, z, -1.6666654611E-1f);
+    ps = rrt_fma(ps * z, r, r);
+    float pc = 2.443315711809948E-005f;
+    pc = rrt_fma(pc, z, -1.388731625493765E-003f);
+    pc = rrt_fma(pc, z, 4.166664568298827E-002f);
+    pc = rrt_fma(pc * z, z, rrt_fma(-0.5f, z, 1.0f));
+    int q = (j >> 1) & 3;
+    float s_val = (q & 1) ? pc : ps;
+    float c_val = (q & 1) ? ps : pc;
+    int s_neg = ((q & 2) != 0) ^ (x < 0.0f);
+    int c_neg = (q == 1) | (q == 2);
+    *sn = s_neg ? -s_val : s_val;
+    *cs = c_neg ? -c_val : c_val;
+}
+RRT_FN float rrt_sinf(float x) { float s, c; rrt_sincosf(x, &s, &c); return s; }
+RRT_FN float rrt_cosf(float x) { float s, c; rrt_sincosf(x, &s, &c); return c; }
+
+/* atan for any finite x */
+RRT_FN float rrt_atanf(float x) {
+    float ax = rrt_abs(x);
+    float y0, t;
+    if (ax > 2.414213562373095f) { y0 = 1.5707963267948966f; t = -1.0f / ax; }
+    else if (ax > 0.4142135623730950f) { y0 = 0.7853981633974483f; t = (ax - 1.0f) / (ax + 1.0f); }
+    else { y0 = 0.0f; t = ax; }
+    float z = t * t;
+    float p = 8.05374449538e-2f;
+    p = rrt_fma(p, z, -1.38776856032E-1f);
+    p = rrt_fma(p, z, 1.99777106478E-1f);
+    p = rrt_fma(p, z, -3.33329491539E-1f);
+    float r = y0 + rrt_fma(p * z, t, t);
+    return (x < 0.0f) ? -r : r;
+}
+
+RRT_FN float rrt_atan2f(float y, float x) {
+    const float PI_F = 3.14159265358979323846f;
+    const float PIO2_F = 1.5707963267948966f;
+    if (x != x || y != y) return x + y;
+    if (x == 0.0f) {
+        if (y == 0.0f) return 0.0f;
+        return (y < 0.0f) ? -PIO2_F : PIO2_F;
+    }
+    if (y == 0.0f) return (x < 0.0f) ? PI_F : 0.0f;
+    float w = 0.0f;
+    if (x < 0.0f) w = (y < 0.0f) ? -PI_F : PI_F;
+    return w + rrt_atanf(y / x);
+}
+
+/* asin for |x| <= 1 */
+RRT_FN float rrt_asinf(float x) {
+    float a = rrt_abs(x);
+    if (!(a <= 1.0f)) return rrt_u2f(0x7fc00000u);
+    if (a < 1.0e-4f) return x;
+    int flag = a > 0.5f;
+    float z, t;
+    if (flag) { z = 0.5f * (1.0f - a); t = rrt_sqrt(z); }
+    else { t = a; z = t * t; }
+    float p = 4.2163199048E-2f;
+    p = rrt_fma(p, z, 2.4181311049E-2f);
+    p = rrt_fma(p, z, 4.5470025998E-2f);
+    p = rrt_fma(p, z, 7.4953002686E-2f);
+    p = rrt_fma(p, z, 1.6666752422E-1f);
+    float r = rrt_fma(p * z, t, t);
+    if (flag) { r = r + r; r = 1.5707963267948966f - r; }
+    return (x < 0.0f) ? -r : r;
+}
+
+#endif /* RRT_MATH_H */
