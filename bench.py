@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the geodesic ray-march hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one full frame of the BASELINE.json workload: 3840x2160, Kerr a = 0.9,
+full volumetric disk + dust + Doppler/redshift, the reference's start-up camera
+(src/main.cpp:128-130), time = 1.0, default CameraEffects, synthetic 2048x1024 sky
+(seed 1) already resident in HBM.  With N > 1 (launched by torch.distributed.run, one
+rank per GPU) the SAME frame is split into interleaved 16-row tiles across the ranks
+and assembled on rank 0 by one RCCL gather: strong scaling.
+
+Rank 0 prints one JSON line.  `value` = Mrays/s (= Mpixels/s) of the whole job.
+`roofline` prices the dominant kernel (raymarch_pixels) against the FP32 vector-ALU
+issue rate, which is what bounds it; the HBM view that the north star
+asks for is reported alongside.  `cpu_baseline` is the CPU oracle (OpenMP) on a strided
+sample of the same frame -- a reported baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# FP32 VALU issue peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one unfused op per lane per
+# clock (MI355X_MICROARCH.md: SIMD-32, 2-cycle wave64 issue; measured 58-64 T/s at the
+# clock the chip holds under load: profiles/r01_valu_microbench.txt).
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+HBM_PEAK_GBS = 8000.0
+ALGO_BYTES_PER_RAY = 52.0          # 4 B RGBA8 store + 3 bilinear fetches x 4 texels x 4 B
+
+
+def ops_per_ray(steps, noise, dens, samples):
+    """source-level IEEE ops, FMA not assumed."""
+    return 297.0 * steps + 223.0 * noise + 60.0 * dens + 40.0 * samples + 150.0
+
+
+def cpu_baseline(width, height, spin, stride, sky):
+    """Oracle (OpenMP, libm) on pixels (x, y) with x % stride == y % stride == 0 of the same frame."""
+    import numpy as np
+    from oracle import pyoracle as po
+    import relativisticraytracer_amd as rrt
+    po.build()
+    a = rrt.CameraState.default().as_array()
+    cam = po.camera(a[0], a[1], a[2], a[3])
+    prm = po.default_params(spin=spin)
+    nthreads = po.max_threads()
+    t0 = time.perf_counter()
+    r = po.render(cam, po.default_effects(), prm, 1.0, width, height, sky, stride=(stride, stride),
+                  want=("diag",), n_threads=nthreads)
+    dt = time.perf_counter() - t0
+    sel = np.zeros((height, width), bool); sel[::stride, ::stride] = True
+    sel = sel.reshape(-1)
+    n = int(sel.sum())
+    means = {k: float(r[k][sel].mean()) for k in ("steps", "n_noise", "n_dens", "n_samples")}
+    return {"value": n / dt / 1e6, "unit": "Mrays/s", "cores": nthreads, "kind": "port",
+            "sample": f"every {stride}th pixel in x and y of the same {width}x{height} frame "
+                      f"({n} rays, {dt:.1f} s wall, oracle/rrt_oracle.c, libm math, OpenMP dynamic rows)"}, means
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--spin", type=float, default=0.9)
+    ap.add_argument("--tile-rows", type=int, default=16)
+    ap.add_argument("--cpu-stride", type=int, default=8, help="CPU baseline sample stride (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import relativisticraytracer_amd as rrt
+    from relativisticraytracer_amd import sharding
+    from relativisticraytracer_amd.sky import synthetic_sky
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    w, h, R = args.width, args.height, args.tile_rows
+    sky_np = synthetic_sky(2048, 1024, seed=1)
+    tex = rrt.SkyTexture(sky_np)
+    cam, fx = rrt.CameraState.default(), rrt.CameraEffects()
+    prm = rrt.RenderParams(spin=args.spin, volumetrics=1)
+
+    kernel_ms = []
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps + args.warmup)]
+    it = {"i": 0}
+
+    def render(buf):
+        e0, e1 = ev[it["i"]]
+        e0.record()                      # torch's current stream == the stream the launch goes to
+        rrt.launch_raymarch_tiles(buf, w, h, R, rank, world, 1.0, cam, tex, fx, prm)
+        e1.record()
+
+    def assemble(frame, buf, shard):
+        rrt.assemble_tiles(frame, buf, w, h, R, shard, world)
+
+    fs = sharding.FrameSharder(w, h, R, rank, world, dev, render, assemble)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        fs.step(); it["i"] += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fs.step(); it["i"] += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in ev[args.warmup:]]
+
+    if rank == 0:
+        rays = w * h
+        ms_per_step = dt / args.steps * 1e3
+        value = rays * args.steps / dt / 1e6
+        k_ms = float(np.mean(kernel_ms))
+        my_rays = sharding.shard_rows(h, R, 0, world) * w
+
+        cpu, means = (None, None)
+        if world == 1 and args.cpu_stride > 0:
+            cpu, means = cpu_baseline(w, h, args.spin, args.cpu_stride, sky_np)
+        if means is None:   # per-ray work from a small oracle sample even when the baseline is skipped
+            _, means = cpu_baseline(w, h, args.spin, 48, sky_np)
+        opr = ops_per_ray(means["steps"], means["n_noise"], means["n_dens"], means["n_samples"])
+        tops = opr * my_rays / (k_ms * 1e-3) / 1e12
+        hbm_gbs = ALGO_BYTES_PER_RAY * my_rays / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == f"{w}x{h}_a{args.spin:g}_vol" and world == 1:
+                    traffic = tj.get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "fps": round(1e3 / ms_per_step, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{w}x{h} Kerr a={args.spin:g} full volumetric disk+dust, default camera "
+                                   f"(0,10,-60) yaw 0 pitch -10, t=1.0, default effects, synthetic 2048x1024 sky seed 1",
+                       "rays_per_frame": rays, "max_steps": 2000,
+                       "parallelism": f"rowtiles{R}x{world}" if world > 1 else "single"},
+            "roofline": {"bound": "valu", "achieved": round(tops, 3), "peak": round(VALU_PEAK_TOPS, 2),
+                         "unit": "TFLOP/s", "frac": round(tops / VALU_PEAK_TOPS, 4), "traffic": traffic,
+                         "kernel": "raymarch_pixels", "kernel_ms": round(k_ms, 3),
+                         "ops_per_ray": round(opr, 1), "per_ray_means": {k: round(v, 2) for k, v in means.items()},
+                         "note": "source-level unfused FP32 ops (SURVEY 8d formula) / HIP-event kernel time; "
+                                 "peak = 256CU x 4SIMD x 32 lanes x 2.4 GHz",
+                         "hbm": {"bound": "hbm", "achieved": round(hbm_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(hbm_gbs / HBM_PEAK_GBS, 6),
+                                 "note": "algorithmic 52 B/ray; the path is not HBM-bound"}},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    tex.destroy()
+
+
+if __name__ == "__main__":
+    main()

@@ -43,7 +43,7 @@ class Params(C.Structure):
 
 class Diag(C.Structure):
     _fields_ = [("steps", _ip), ("hit", _ip), ("pos", _fp), ("vel", _fp), ("rad", _fp),
-                ("n_noise", _ip), ("n_samples", _ip)]
+                ("n_noise", _ip), ("n_samples", _ip), ("n_dens", _ip)]
 
 
 def build(ref=False, quiet=True):
@@ -122,6 +122,7 @@ def render(cam, fx, prm, time, width, height, sky, rect=None, stride=(1, 1),
         out["hit"] = np.zeros(n, np.int32); d.hit = out["hit"].ctypes.data_as(_ip)
         out["n_noise"] = np.zeros(n, np.int32); d.n_noise = out["n_noise"].ctypes.data_as(_ip)
         out["n_samples"] = np.zeros(n, np.int32); d.n_samples = out["n_samples"].ctypes.data_as(_ip)
+        out["n_dens"] = np.zeros(n, np.int32); d.n_dens = out["n_dens"].ctypes.data_as(_ip)
         out["pos"] = np.zeros((n, 3), np.float32); d.pos = _p(out["pos"])
         out["vel"] = np.zeros((n, 3), np.float32); d.vel = _p(out["vel"])
         out["rad"] = np.zeros((n, 4), np.float32); d.rad = _p(out["rad"])

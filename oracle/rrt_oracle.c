@@ -38,6 +38,7 @@ typedef struct { float x, y, z; } f3;
 typedef struct {
     int mode;        /* RRTO_MATH_* */
     int n_noise;     /* noise3D evaluation counter (diagnostic) */
+    int n_dens;      /* density calls past the radial gate (diagnostic) */
 } ctx_t;
 
 static inline float m_pow(const ctx_t* c, float x, float y) { return c->mode ? rrt_powf(x, y) : powf(x, y); }
@@ -182,6 +183,7 @@ static inline float disk_temperature(const ctx_t* c, float r) {
 static inline float accretion_density(ctx_t* c, f3 p, float time) {
     float r = length3(mk3(p.x, 0.0f, p.z));
     if (r < ISCO_RADIUS || r > DISK_OUT_M) return 0.0f;
+    c->n_dens++;
 
     float edge_falloff = 1.0f;
     float edge_start = DISK_OUT_M * 0.85f;
@@ -220,6 +222,7 @@ static inline float accretion_density(ctx_t* c, f3 p, float time) {
 static inline float dust_density(ctx_t* c, f3 p, float time) {
     float r = length3(mk3(p.x, 0.0f, p.z));
     if (r < ISCO_RADIUS || r > DISK_OUT_M) return 0.0f;
+    c->n_dens++;
 
     float edge_falloff = smoothstepf(DISK_OUT_M, DISK_OUT_M * 0.8f, r);
     float inner_taper = smoothstepf(ISCO_RADIUS, ISCO_RADIUS + 5.0f, r);
@@ -339,7 +342,7 @@ typedef struct {
     uint8_t rgba[4];
     float ldr[3];
     float hdr[3];
-    int steps, hit, n_noise, n_samples;
+    int steps, hit, n_noise, n_samples, n_dens;
     f3 p, v;
     float rad[4];
 } pixel_out;
@@ -347,7 +350,7 @@ typedef struct {
 static void trace_pixel(const rrto_camera* cam, const rrto_effects* fx, const rrto_params* prm,
                         float time, int width, int height, int x, int y,
                         const uint8_t* sky, int sw, int sh, pixel_out* o) {
-    ctx_t c = {prm->math_mode, 0};
+    ctx_t c = {prm->math_mode, 0, 0};
     const float spin = prm->spin;
 
     float uvx = (float)x / width;
@@ -492,6 +495,7 @@ static void trace_pixel(const rrto_camera* cam, const rrto_effects* fx, const rr
     o->hit = hit_horizon;
     o->n_noise = c.n_noise;
     o->n_samples = n_samples;
+    o->n_dens = c.n_dens;
     o->p = p; o->v = vel;
     o->rad[0] = intensity_r; o->rad[1] = intensity_g; o->rad[2] = intensity_b; o->rad[3] = transmittance;
 }
@@ -525,6 +529,7 @@ int rrto_render(const rrto_camera* cam, const rrto_effects* fx, const rrto_param
                 if (diag->hit) diag->hit[di] = o.hit;
                 if (diag->n_noise) diag->n_noise[di] = o.n_noise;
                 if (diag->n_samples) diag->n_samples[di] = o.n_samples;
+                if (diag->n_dens) diag->n_dens[di] = o.n_dens;
                 if (diag->pos) { diag->pos[3 * di] = o.p.x; diag->pos[3 * di + 1] = o.p.y; diag->pos[3 * di + 2] = o.p.z; }
                 if (diag->vel) { diag->vel[3 * di] = o.v.x; diag->vel[3 * di + 1] = o.v.y; diag->vel[3 * di + 2] = o.v.z; }
                 if (diag->rad) memcpy(diag->rad + 4 * di, o.rad, 16);
@@ -562,8 +567,8 @@ static inline f3 ld3(const float* a, int i) { return mk3(a[3 * i], a[3 * i + 1],
 static inline void st3(float* a, int i, f3 v) { a[3 * i] = v.x; a[3 * i + 1] = v.y; a[3 * i + 2] = v.z; }
 
 void rrto_hash31(int n, const float* p, float* out) { for (int i = 0; i < n; ++i) out[i] = hash31(ld3(p, i)); }
-void rrto_noise3d(int n, const float* p, float* out) { ctx_t c = {0, 0}; for (int i = 0; i < n; ++i) out[i] = noise3d(&c, ld3(p, i)); }
-void rrto_fbm(int n, const float* p, int oct, float* out) { ctx_t c = {0, 0}; for (int i = 0; i < n; ++i) out[i] = fbm(&c, ld3(p, i), oct); }
+void rrto_noise3d(int n, const float* p, float* out) { ctx_t c = {0, 0, 0}; for (int i = 0; i < n; ++i) out[i] = noise3d(&c, ld3(p, i)); }
+void rrto_fbm(int n, const float* p, int oct, float* out) { ctx_t c = {0, 0, 0}; for (int i = 0; i < n; ++i) out[i] = fbm(&c, ld3(p, i), oct); }
 void rrto_geodesic_acc(int n, const float* p, const float* v, float spin, float* out) {
     for (int i = 0; i < n; ++i) st3(out, i, geodesic_acc(ld3(p, i), ld3(v, i), spin));
 }
@@ -571,16 +576,16 @@ void rrto_rk4(int n, float* p, float* v, const float* h, float spin) {
     for (int i = 0; i < n; ++i) { f3 pp = ld3(p, i), vv = ld3(v, i); integrate_rk4(&pp, &vv, h[i], spin); st3(p, i, pp); st3(v, i, vv); }
 }
 void rrto_redshift(int n, const float* p, const float* vel, float spin, int mode, float* out) {
-    ctx_t c = {mode, 0}; for (int i = 0; i < n; ++i) out[i] = redshift_factor(&c, ld3(p, i), ld3(vel, i), spin);
+    ctx_t c = {mode, 0, 0}; for (int i = 0; i < n; ++i) out[i] = redshift_factor(&c, ld3(p, i), ld3(vel, i), spin);
 }
 void rrto_disk_temperature(int n, const float* r, int mode, float* out) {
-    ctx_t c = {mode, 0}; for (int i = 0; i < n; ++i) out[i] = disk_temperature(&c, r[i]);
+    ctx_t c = {mode, 0, 0}; for (int i = 0; i < n; ++i) out[i] = disk_temperature(&c, r[i]);
 }
 void rrto_accretion_density(int n, const float* p, float time, int mode, float* out) {
-    ctx_t c = {mode, 0}; for (int i = 0; i < n; ++i) out[i] = accretion_density(&c, ld3(p, i), time);
+    ctx_t c = {mode, 0, 0}; for (int i = 0; i < n; ++i) out[i] = accretion_density(&c, ld3(p, i), time);
 }
 void rrto_dust_density(int n, const float* p, float time, int mode, float* out) {
-    ctx_t c = {mode, 0}; for (int i = 0; i < n; ++i) out[i] = dust_density(&c, ld3(p, i), time);
+    ctx_t c = {mode, 0, 0}; for (int i = 0; i < n; ++i) out[i] = dust_density(&c, ld3(p, i), time);
 }
 void rrto_smoothstep(int n, const float* e0, const float* e1, const float* x, float* out) {
     for (int i = 0; i < n; ++i) out[i] = smoothstepf(e0[i], e1[i], x[i]);
@@ -596,10 +601,10 @@ void rrto_bloom(int n, const float* rgb, float threshold, float* out) {
 }
 void rrto_sky_sample(int n, const float* dir, float off, const uint8_t* sky, int sw, int sh,
                      int frac_bits, int mode, float* out) {
-    ctx_t c = {mode, 0}; for (int i = 0; i < n; ++i) sample_sky(&c, ld3(dir, i), off, sky, sw, sh, frac_bits, out + 4 * i);
+    ctx_t c = {mode, 0, 0}; for (int i = 0; i < n; ++i) sample_sky(&c, ld3(dir, i), off, sky, sw, sh, frac_bits, out + 4 * i);
 }
 void rrto_math(int fn, int mode, int n, const float* a, const float* b, float* out) {
-    ctx_t c = {mode, 0};
+    ctx_t c = {mode, 0, 0};
     for (int i = 0; i < n; ++i) {
         switch (fn) {
             case 0: out[i] = m_exp(&c, a[i]); break;

@@ -69,6 +69,7 @@ typedef struct {             /* per-ray diagnostics, all optional */
     float* rad;              /* 4 per ray: intensity r,g,b, transmittance */
     int32_t* n_noise;        /* noise3D evaluations */
     int32_t* n_samples;      /* RT samples accumulated (d > 0.001 block entered) */
+    int32_t* n_dens;         /* density-function calls that passed the radial gate */
 } rrto_diag;
 
 void rrto_default_params(rrto_params* p);

@@ -1,0 +1,84 @@
+"""Image-plane sharding for multi-GPU rendering (no counterpart in the
+single-GPU reference).
+
+The frame is cut into row tiles of `tile_rows` image rows; tile t belongs to shard
+t mod n_shards (interleaved, because contiguous row blocks are badly load-balanced:
+the rows through the disk and the shadow cost several times the sky rows).  Every
+rank renders its tiles into one compact buffer (tile-major, each tile bottom-up --
+the layout rrt_launch_raymarch_tiles writes), ONE gather moves the buffers to rank 0,
+and rank 0 scatters them into the bottom-up frame (rrt_assemble_tiles).
+
+This module is backend-agnostic plumbing over torch.distributed: with the "nccl"
+backend (= RCCL over xGMI) the buffers are device tensors and `render`/`assemble`
+are the HIP entry points; the CPU tests drive the same code over "gloo" with the
+oracle as the renderer.
+"""
+import numpy as np
+
+
+def tile_plan(height, tile_rows, shard, n_shards):
+    """[(tile index t, first image row y0, rows in tile)] for `shard`, in buffer order."""
+    if height <= 0 or tile_rows <= 0 or n_shards <= 0 or not (0 <= shard < n_shards):
+        raise ValueError("bad tile plan arguments")
+    n_tiles = (height + tile_rows - 1) // tile_rows
+    return [(t, t * tile_rows, min(tile_rows, height - t * tile_rows)) for t in range(shard, n_tiles, n_shards)]
+
+
+def shard_rows(height, tile_rows, shard, n_shards):
+    return sum(rows for _, _, rows in tile_plan(height, tile_rows, shard, n_shards))
+
+
+def max_shard_rows(height, tile_rows, n_shards):
+    return max(shard_rows(height, tile_rows, s, n_shards) for s in range(n_shards))
+
+
+def assemble_numpy(frame, tiles, width, height, tile_rows, shard, n_shards):
+    """Host restatement of rrt_assemble_tiles (used by the CPU tests).
+    frame: (height, width, 4) bottom-up; tiles: (>= shard_rows, width, 4)."""
+    for k, (t, y0, rows) in enumerate(tile_plan(height, tile_rows, shard, n_shards)):
+        src = tiles[k * tile_rows:k * tile_rows + rows]          # tile-major; tile stored bottom-up
+        frame[height - (y0 + rows):height - y0] = src
+    return frame
+
+
+def extract_numpy(frame, width, height, tile_rows, shard, n_shards, pad_rows=None):
+    """Inverse of assemble_numpy: the compact tile buffer of `shard` cut from a full frame."""
+    n = shard_rows(height, tile_rows, shard, n_shards)
+    out = np.zeros((pad_rows if pad_rows is not None else n, width, 4), frame.dtype)
+    for k, (t, y0, rows) in enumerate(tile_plan(height, tile_rows, shard, n_shards)):
+        out[k * tile_rows:k * tile_rows + rows] = frame[height - (y0 + rows):height - y0]
+    return out
+
+
+class FrameSharder:
+    """One rank's view of a sharded frame.
+
+    render(buf)            fills this rank's tile buffer (a (pad_rows*width*4,) uint8 tensor)
+    assemble(frame, buf, shard)   scatters one shard's buffer into the full frame (rank 0 only)
+    """
+
+    def __init__(self, width, height, tile_rows, rank, world, device, render, assemble, group=None):
+        import torch
+        self.torch = torch
+        self.width, self.height, self.tile_rows = width, height, tile_rows
+        self.rank, self.world, self.group = rank, world, group
+        self.pad_rows = max_shard_rows(height, tile_rows, world)
+        self.n_bytes = self.pad_rows * width * 4
+        self.render, self.assemble = render, assemble
+        self.local = torch.zeros(self.n_bytes, dtype=torch.uint8, device=device)
+        self.frame = torch.zeros(height * width * 4, dtype=torch.uint8, device=device) if rank == 0 else None
+        self.gathered = ([torch.zeros(self.n_bytes, dtype=torch.uint8, device=device) for _ in range(world)]
+                         if (rank == 0 and world > 1) else None)
+
+    def step(self):
+        """Render this rank's tiles, gather to rank 0, assemble there.  Returns the frame on rank 0."""
+        self.render(self.local)
+        if self.world == 1:
+            self.assemble(self.frame, self.local, 0)
+            return self.frame
+        import torch.distributed as dist
+        dist.gather(self.local, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
+        if self.rank == 0:
+            for s in range(self.world):
+                self.assemble(self.frame, self.gathered[s], s)
+        return self.frame

@@ -1,0 +1,57 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def po():
+    """The CPU oracle binding (test infrastructure)."""
+    from oracle import pyoracle
+    pyoracle.build()          # compiles oracle/librrt_oracle.so if missing or stale (gcc only)
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def units_ref():
+    return dict(np.load(os.path.join(GOLDEN, "units_ref.npz")))
+
+
+@pytest.fixture(scope="session")
+def frames_gold():
+    return dict(np.load(os.path.join(GOLDEN, "frames_oracle.npz")))
+
+
+@pytest.fixture(scope="session")
+def camera_ref():
+    return dict(np.load(os.path.join(GOLDEN, "camera_ref.npz")))
+
+
+@pytest.fixture(scope="session")
+def sky():
+    from relativisticraytracer_amd.sky import synthetic_sky
+    return synthetic_sky()
+
+
+def same_bits(a, b):
+    """Bit equality of float arrays, except that +0 and -0 compare equal."""
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    return a.shape == b.shape and bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))))
+
+
+def ulp_diff(a, b):
+    """|a-b| in units of ulp(b) (float32)."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    ulp = np.spacing(np.abs(b).astype(np.float32)).astype(np.float64)
+    return np.abs(a - b) / ulp

@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/.
+
+Runs in the BUILD CONTAINER only (it needs /root/reference for the unit
+vectors).  Two kinds of fixture, kept in separate files so their provenance
+stays clear:
+
+  units_ref.npz      inputs + outputs of the REFERENCE's own device functions
+                     (oracle/_ref/libref_units.so = /root/reference/include/*.h
+                     compiled by g++, see oracle/ref_units.cpp).  These pin the
+                     oracle restatement to the reference, bit for bit.
+  camera_ref.npz     catmull_rom / lerp_angle samples and the three keyframe
+                     tables from the reference's src/camera_paths.cpp.
+  frames_oracle.npz  small frames rendered by the oracle RESTATEMENT (both math
+                     modes).  The reference cannot render a frame here (its
+                     kernel needs nvcc), so these are regression pins of the
+                     restatement, NOT reference outputs.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+
+from oracle import pyoracle as po  # noqa: E402
+from relativisticraytracer_amd.sky import synthetic_sky  # noqa: E402
+
+SPINS = (0.0, 0.9, 0.99)
+TIMES = (0.0, 1.0, 12.5)
+
+
+def unit_inputs():
+    rng = np.random.default_rng(20260130)
+    n = 1024
+    d = {}
+    # positions with r in [1.5, 300] (log-uniform) + a few inside r < 1 for the geodesics.h:33 branch
+    dirs = rng.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    r = np.exp(rng.uniform(np.log(1.5), np.log(300.0), n))
+    r[:16] = rng.uniform(0.05, 0.999, 16)
+    d["geo_p"] = (dirs * r[:, None]).astype(np.float32)
+    v = rng.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    d["geo_v"] = (v * rng.uniform(0.8, 1.25, (n, 1))).astype(np.float32)
+    d["rk4_h"] = np.float32(0.3) * np.float32([1.0, 0.3, 0.1])[rng.integers(0, 3, n)]
+    d["rk4_h"] = d["rk4_h"].astype(np.float32)
+    # lattice points for hash31: small, negative, large, and the exact-integer products at +-10000
+    lat = rng.integers(-400, 400, (n, 3)).astype(np.float32)
+    lat[:64] = rng.integers(-20000, 20000, (64, 3))
+    lat[64:70] = [[10000, 0, 0], [-10000, 0, 0], [0, 10000, -10000], [0, 0, 0], [-1, -1, -1], [10000, 10000, 10000]]
+    d["lattice"] = lat.astype(np.float32)
+    pts = rng.uniform(-60, 60, (n, 3)).astype(np.float32)
+    pts[:32] = rng.uniform(-3000, 3000, (32, 3))
+    pts[32:40] = np.round(pts[32:40])             # exactly on lattice planes
+    d["noise_p"] = pts.astype(np.float32)
+    # in-zone sample points
+    ang = rng.uniform(-np.pi, np.pi, n)
+    rc = rng.uniform(9.0, 26.0, n)
+    y_disk = rng.uniform(-4.0, 4.0, n); y_disk[: n // 2] = rng.normal(0, 0.5, n // 2)
+    d["disk_p"] = np.stack([rc * np.cos(ang), y_disk, rc * np.sin(ang)], 1).astype(np.float32)
+    y_cloud = rng.uniform(-0.75, 0.75, n); y_cloud[: n // 2] = rng.normal(0, 0.15, n // 2)
+    d["cloud_p"] = np.stack([rc * np.cos(ang), y_cloud, rc * np.sin(ang)], 1).astype(np.float32)
+    d["temp_r"] = rng.uniform(2.0, 40.0, n).astype(np.float32)
+    d["ss_e0"] = rng.uniform(-1, 1, n).astype(np.float32)
+    d["ss_e1"] = (d["ss_e0"] + rng.choice([-1.0, 1.0], n) * rng.uniform(0.05, 2, n)).astype(np.float32)
+    d["ss_x"] = rng.uniform(-2, 2, n).astype(np.float32)
+    d["uv"] = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    d["rgb"] = rng.exponential(0.6, (n, 3)).astype(np.float32)
+    return d
+
+
+def make_units():
+    if not po.ref_available():
+        po.build(ref=True)
+    ref = po.ref_units()
+    d = unit_inputs()
+    out = dict(d)
+    out["constants"] = po.ref_constants()
+    for a in SPINS:
+        tag = f"{a:g}"
+        out[f"geodesic_acc_a{tag}"] = ref.geodesic_acc(d["geo_p"], d["geo_v"], a)
+        p, v = ref.rk4(d["geo_p"], d["geo_v"], d["rk4_h"], a)
+        out[f"rk4_p_a{tag}"], out[f"rk4_v_a{tag}"] = p, v
+        out[f"redshift_disk_a{tag}"] = ref.redshift(d["disk_p"], d["geo_v"], a)
+    out["hash31"] = ref.hash31(d["lattice"])
+    out["noise3d"] = ref.noise3d(d["noise_p"])
+    out["fbm2"] = ref.fbm(d["noise_p"], 2)
+    out["fbm5"] = ref.fbm(d["noise_p"], 5)
+    for t in TIMES:
+        out[f"accretion_t{t:g}"] = ref.accretion_density(d["disk_p"], t)
+        out[f"dust_t{t:g}"] = ref.dust_density(d["cloud_p"], t)
+    out["disk_temperature"] = ref.disk_temperature(d["temp_r"])
+    out["smoothstep"] = ref.smoothstep(d["ss_e0"], d["ss_e1"], d["ss_x"])
+    out["lens_k0.15"] = ref.lens(d["uv"], 0.15)
+    out["vignette_i0.4"] = ref.vignette(d["rgb"], d["uv"], 0.4)
+    out["bloom_t0.8"] = ref.bloom(d["rgb"], 0.8)
+    np.savez_compressed(os.path.join(HERE, "units_ref.npz"), **out)
+    print("units_ref.npz:", len(out), "arrays")
+
+
+def make_camera():
+    rc = po.RefCamera()
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-80, 80, (64, 4, 3)).astype(np.float32)
+    ts = rng.uniform(0, 1, 64).astype(np.float32)
+    cr = np.stack([rc.catmull_rom(pts[i, 0], pts[i, 1], pts[i, 2], pts[i, 3], ts[i]) for i in range(64)])
+    ab = rng.uniform(-540, 540, (256, 2)).astype(np.float32)
+    tt = rng.uniform(0, 1, 256).astype(np.float32)
+    la = np.array([rc.lerp_angle(ab[i, 0], ab[i, 1], tt[i]) for i in range(256)], np.float32)
+    out = {"cr_pts": pts, "cr_t": ts, "cr_out": cr, "la_ab": ab, "la_t": tt, "la_out": la}
+    for idx, (name, keys) in enumerate(rc.paths()):
+        out[f"path{idx}_keys"] = keys
+        out[f"path{idx}_name"] = np.frombuffer(name.encode(), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "camera_ref.npz"), **out)
+    print("camera_ref.npz:", len(out), "arrays")
+
+
+# frame cases: name -> (w, h, spin, volumetrics, camera(pos,yaw,pitch), time, effects overrides)
+FRAME_CASES = {
+    "G1": (128, 128, 0.0, 1, ((0.0, 10.0, -60.0), 0.0, -10.0), 1.0, {}),
+    "G2": (64, 36, 0.9, 0, ((0.0, 10.0, -60.0), 0.0, -10.0), 1.0, {}),
+    "G3": (64, 36, 0.9, 1, ((0.0, 10.0, -60.0), 0.0, -10.0), 1.0, {}),
+    "G4": (64, 36, 0.99, 1, ((0.0, 10.0, -60.0), 0.0, -10.0), 1.0, {}),
+    "G5": (64, 36, 0.9, 1, ((35.0, 0.8, 10.0), -106.0, -1.2), 12.5, {"use_ca": 1}),
+}
+
+
+def frame_camera(spec):
+    import relativisticraytracer_amd as rrt
+    a = rrt.CameraState.from_angles(*spec).as_array()
+    return a, po.camera(a[0], a[1], a[2], a[3])
+
+
+def make_frames():
+    sky = synthetic_sky()
+    out = {}
+    for name, (w, h, spin, vol, camspec, t, fxkw) in FRAME_CASES.items():
+        cam_arr, cam = frame_camera(camspec)
+        out[f"{name}_camera"] = cam_arr
+        for mode, mtag in ((po.MATH_LIBM, "libm"), (po.MATH_PORTABLE, "portable")):
+            prm = po.default_params(spin=spin, volumetrics=vol, math_mode=mode)
+            r = po.render(cam, po.default_effects(**fxkw), prm, t, w, h, sky, want=("rgba8", "ldr", "diag"))
+            out[f"{name}_{mtag}_rgba8"] = r["rgba8"]
+            if name != "G1":
+                out[f"{name}_{mtag}_ldr"] = r["ldr"]
+            out[f"{name}_{mtag}_steps"] = r["steps"].astype(np.int16)
+            out[f"{name}_{mtag}_hit"] = r["hit"].astype(np.uint8)
+            if mtag == "portable" and name != "G1":
+                out[f"{name}_{mtag}_pos"] = r["pos"]
+                out[f"{name}_{mtag}_vel"] = r["vel"]
+                out[f"{name}_{mtag}_rad"] = r["rad"]
+        print(name, "done")
+    np.savez_compressed(os.path.join(HERE, "frames_oracle.npz"), **out)
+    print("frames_oracle.npz:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    po.build(ref=True)
+    make_units()
+    make_camera()
+    make_frames()

@@ -1,0 +1,58 @@
+"""Helpers shared by the -m gpu tests: torch is only the device-memory plumbing."""
+import ctypes as C
+
+import numpy as np
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    import torch
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def unit(name, *args):
+    """Call rrt_unit_<name> through the C ABI; tensors are passed as device pointers."""
+    import torch
+    from relativisticraytracer_amd import _lib
+    lib = _lib.load()
+    conv = []
+    for a in args:
+        if hasattr(a, "data_ptr"):
+            conv.append(C.c_void_p(a.data_ptr()))
+        else:
+            conv.append(a)
+    conv.append(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(getattr(lib, "rrt_unit_" + name)(*conv), "rrt_unit_" + name)
+
+
+def render_gpu(w, h, spin, vol, cam, time, sky_tex, fx=None, debug=True, max_steps=2000, frac_bits=8):
+    """Full-frame render through rrt_launch_raymarch(_ex); returns numpy arrays."""
+    import torch
+    import relativisticraytracer_amd as rrt
+    fx = fx or rrt.CameraEffects()
+    prm = rrt.RenderParams(spin=spin, volumetrics=vol, max_steps=max_steps, sky_frac_bits=frac_bits)
+    out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+    res = {}
+    if debug:
+        n = w * h
+        bufs = dict(ldr=torch.zeros(n * 4, device="cuda"), hdr=torch.zeros(n * 4, device="cuda"),
+                    steps=torch.zeros(n, dtype=torch.int32, device="cuda"),
+                    hit=torch.zeros(n, dtype=torch.int32, device="cuda"),
+                    pos=torch.zeros(n * 3, device="cuda"), vel=torch.zeros(n * 3, device="cuda"),
+                    rad=torch.zeros(n * 4, device="cuda"))
+        rrt.launch_raymarch_debug(out, w, h, time, cam, sky_tex, fx, prm, **bufs)
+        torch.cuda.synchronize()
+        res = {k: v.cpu().numpy() for k, v in bufs.items()}
+        res["ldr"] = res["ldr"].reshape(h, w, 4); res["hdr"] = res["hdr"].reshape(h, w, 4)
+        res["pos"] = res["pos"].reshape(n, 3); res["vel"] = res["vel"].reshape(n, 3)
+        res["rad"] = res["rad"].reshape(n, 4)
+    else:
+        rrt.launch_raymarch(out, w, h, time, cam, sky_tex, fx, prm)
+        torch.cuda.synchronize()
+    res["rgba8"] = out.cpu().numpy().reshape(h, w, 4)
+    return res

@@ -1,0 +1,190 @@
+"""Frame-level parity of the HIP path (through the C ABI) against the CPU oracle.
+
+Bars (north_star: "within 1e-4 relative per channel"):
+  * vs the oracle in PORTABLE math mode (same csrc/rrt_math.h on both sides):
+    RGBA8 bytes identical, float RGB / per-ray state bit-identical;
+  * vs the oracle in LIBM mode (glibc transcendentals, the independent check):
+    float RGB within 1e-4 relative (+1e-5 absolute floor for near-black
+    pixels), RGBA8 within 1 LSB, on >= 99.5 % of pixels -- the remainder are
+    rays whose hard density gates (raymarcher.cu:71,76,91; densities.h:85)
+    flip on a 1-ulp transcendental difference; their error is bounded too.
+"""
+import numpy as np
+import pytest
+
+from conftest import same_bits
+
+pytestmark = pytest.mark.gpu
+
+CASES = {   # name -> (w, h, spin, vol, (pos, yaw, pitch), time, effect overrides)  == tests/golden/make_golden.py
+    "G1": (128, 128, 0.0, 1, ((0.0, 10.0, -60.0), 0.0, -10.0), 1.0, {}),
+    "G2": (64, 36, 0.9, 0, ((0.0, 10.0, -60.0), 0.0, -10.0), 1.0, {}),
+    "G3": (64, 36, 0.9, 1, ((0.0, 10.0, -60.0), 0.0, -10.0), 1.0, {}),
+    "G4": (64, 36, 0.99, 1, ((0.0, 10.0, -60.0), 0.0, -10.0), 1.0, {}),
+    "G5": (64, 36, 0.9, 1, ((35.0, 0.8, 10.0), -106.0, -1.2), 12.5, {"useChromaticAberration": True}),
+}
+
+
+@pytest.fixture(scope="module")
+def ctx(sky):
+    import torch
+    assert torch.cuda.is_available(), "the -m gpu tests need a GPU"
+    import gpu_util
+    import relativisticraytracer_amd as rrt
+    tex = rrt.SkyTexture(sky)
+    yield gpu_util, rrt, tex
+    tex.destroy()
+
+
+def _render(ctx, name, **kw):
+    g, rrt, tex = ctx
+    w, h, spin, vol, camspec, t, fxkw = CASES[name]
+    cam = rrt.CameraState.from_angles(*camspec)
+    return g.render_gpu(w, h, spin, vol, cam, t, tex, fx=rrt.CameraEffects(**fxkw), **kw), cam
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_golden_frames_byte_identical(ctx, frames_gold, name):
+    r, cam = _render(ctx, name)
+    assert np.array_equal(cam.as_array(), frames_gold[f"{name}_camera"])
+    assert np.array_equal(r["rgba8"], frames_gold[f"{name}_portable_rgba8"])
+    assert np.array_equal(r["steps"], frames_gold[f"{name}_portable_steps"].astype(np.int32))
+    assert np.array_equal(r["hit"], frames_gold[f"{name}_portable_hit"].astype(np.int32))
+    if name != "G1":
+        assert same_bits(r["ldr"], frames_gold[f"{name}_portable_ldr"])
+        assert same_bits(r["pos"], frames_gold[f"{name}_portable_pos"])
+        assert same_bits(r["vel"], frames_gold[f"{name}_portable_vel"])
+        assert same_bits(r["rad"], frames_gold[f"{name}_portable_rad"])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_golden_frames_within_tolerance_of_libm_oracle(ctx, frames_gold, name):
+    r, _ = _render(ctx, name)
+    # geodesic state involves only + - * / sqrt: identical in both oracle modes and on the GPU
+    assert np.array_equal(r["steps"], frames_gold[f"{name}_libm_steps"].astype(np.int32))
+    assert np.array_equal(r["hit"], frames_gold[f"{name}_libm_hit"].astype(np.int32))
+    du8 = np.abs(r["rgba8"].astype(int) - frames_gold[f"{name}_libm_rgba8"].astype(int))
+    assert du8.max() <= 1
+    assert (du8 > 0).mean() <= 0.005
+    if name != "G1":
+        ref = frames_gold[f"{name}_libm_ldr"][..., :3]
+        got = r["ldr"][..., :3]
+        ok = np.abs(got - ref) <= 1e-4 * np.abs(ref) + 1e-5
+        assert ok.mean() >= 0.995
+        assert np.abs(got - ref).max() <= 2e-3
+
+
+def test_live_oracle_random_view(ctx, po, sky):
+    """A view that is in no fixture: oracle rendered live, both math modes."""
+    g, rrt, tex = ctx
+    w, h = 96, 54
+    cam = rrt.CameraState.from_angles((15.0, 3.0, -30.0), -26.6, -5.1)       # a keyframe of path 1
+    fx = rrt.CameraEffects(useChromaticAberration=True, caAmount=0.004)
+    r = g.render_gpu(w, h, 0.9, 1, cam, 6.0, tex, fx=fx)
+    a = cam.as_array()
+    ofx = po.default_effects(use_ca=1, ca_amount=0.004)
+    ocam = po.camera(a[0], a[1], a[2], a[3])
+    o = po.render(ocam, ofx, po.default_params(spin=0.9, math_mode=po.MATH_PORTABLE), 6.0, w, h, sky,
+                  want=("rgba8", "ldr", "hdr", "diag"))
+    assert np.array_equal(r["rgba8"], o["rgba8"])
+    assert same_bits(r["hdr"], o["hdr"]) and same_bits(r["ldr"], o["ldr"])
+    assert np.array_equal(r["steps"], o["steps"])
+    ol = po.render(ocam, ofx, po.default_params(spin=0.9, math_mode=po.MATH_LIBM), 6.0, w, h, sky,
+                   want=("rgba8", "ldr"))
+    ok = np.abs(r["ldr"][..., :3] - ol["ldr"][..., :3]) <= 1e-4 * np.abs(ol["ldr"][..., :3]) + 1e-5
+    assert ok.mean() >= 0.995
+    assert np.abs(r["rgba8"].astype(int) - ol["rgba8"].astype(int)).max() <= 1
+
+
+def test_effect_toggles_and_edge_sizes(ctx, po, sky):
+    """All effects off / ragged sizes (not multiples of the 16x16 block) / 1x1 / max_steps 0."""
+    g, rrt, tex = ctx
+    cam = rrt.CameraState.default()
+    a = cam.as_array(); ocam = po.camera(a[0], a[1], a[2], a[3])
+    fx = rrt.CameraEffects(useBloom=False, useVignette=False, useLensDistortion=False)
+    ofx = po.default_effects(use_bloom=0, use_vignette=0, use_lens=0)
+    for (w, h) in ((37, 23), (1, 1), (17, 16)):
+        r = g.render_gpu(w, h, 0.9, 1, cam, 1.0, tex, fx=fx)
+        o = po.render(ocam, ofx, po.default_params(spin=0.9, math_mode=po.MATH_PORTABLE), 1.0, w, h, sky)
+        assert np.array_equal(r["rgba8"], o["rgba8"]), (w, h)
+    r = g.render_gpu(33, 9, 0.0, 1, cam, 1.0, tex, max_steps=0)
+    o = po.render(ocam, po.default_effects(), po.default_params(max_steps=0, math_mode=po.MATH_PORTABLE),
+                  1.0, 33, 9, sky)
+    assert np.array_equal(r["rgba8"], o["rgba8"])
+    r = g.render_gpu(33, 9, 0.9, 1, cam, 1.0, tex, frac_bits=0)
+    o = po.render(ocam, po.default_effects(), po.default_params(spin=0.9, sky_frac_bits=0, math_mode=po.MATH_PORTABLE),
+                  1.0, 33, 9, sky)
+    assert np.array_equal(r["rgba8"], o["rgba8"])
+
+
+def test_row_and_tile_shards_reassemble_to_the_full_frame(ctx):
+    """Sharded renders must be byte-identical to the single launch."""
+    import torch
+    g, rrt, tex = ctx
+    w, h = 160, 90
+    cam = rrt.CameraState.default(); fx = rrt.CameraEffects(); prm = rrt.RenderParams(spin=0.9)
+    full = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+    rrt.launch_raymarch(full, w, h, 1.0, cam, tex, fx, prm)
+    # contiguous rows written in place into the full frame
+    rows = torch.zeros_like(full)
+    for (y0, y1) in ((0, 31), (31, 64), (64, 90)):
+        off = (h - y1) * w * 4
+        rrt.launch_raymarch_rows(rows[off:], w, h, y0, y1, 1.0, cam, tex, fx, prm)
+    # interleaved tiles, 3 shards of 8-row tiles (ragged last tile: 90 = 11*8 + 2)
+    tiles = torch.zeros_like(full)
+    for n_shards, R in ((3, 8), (8, 16), (2, 7)):
+        tiles.zero_()
+        for s in range(n_shards):
+            nrows = rrt.tile_shard_rows(h, R, s, n_shards)
+            buf = torch.zeros(max(nrows, 1) * w * 4, dtype=torch.uint8, device="cuda")
+            rrt.launch_raymarch_tiles(buf, w, h, R, s, n_shards, 1.0, cam, tex, fx, prm)
+            rrt.assemble_tiles(tiles, buf, w, h, R, s, n_shards)
+        torch.cuda.synchronize()
+        assert torch.equal(tiles, full), (n_shards, R)
+    torch.cuda.synchronize()
+    assert torch.equal(rows, full)
+    assert sum(rrt.tile_shard_rows(h, 8, s, 3) for s in range(3)) == h
+
+
+def test_launch_argument_errors(ctx):
+    import ctypes as C
+    import torch
+    g, rrt, tex = ctx
+    from relativisticraytracer_amd import _lib
+    lib = _lib.load()
+    cam = rrt.CameraState.default(); fx = rrt.CameraEffects()
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    p = C.c_void_p(out.data_ptr())
+    assert lib.rrt_launch_raymarch(None, 4, 4, 0.0, C.byref(cam), tex.handle, C.byref(fx), None, None) == 1
+    assert lib.rrt_launch_raymarch(p, 0, 4, 0.0, C.byref(cam), tex.handle, C.byref(fx), None, None) == 1
+    assert lib.rrt_launch_raymarch(p, 4, 4, 0.0, C.byref(cam), 0, C.byref(fx), None, None) == 4      # bad handle
+    bad = rrt.RenderParams(); bad.reserved[0] = 7
+    assert lib.rrt_launch_raymarch(p, 4, 4, 0.0, C.byref(cam), tex.handle, C.byref(fx), C.byref(bad), None) == 1
+    assert lib.rrt_launch_raymarch_rows(p, 4, 4, 3, 2, 0.0, C.byref(cam), tex.handle, C.byref(fx), None, None) == 1
+    with pytest.raises(rrt.RRTError):
+        rrt.launch_raymarch(out, -1, 4, 0.0, cam, tex, fx)
+
+
+def test_full_size_properties_4k(ctx):
+    """BASELINE config at full size: properties that need no oracle.
+    Two launches give identical bytes (no races); every alpha is 255; the image is left-right
+    symmetric for a = 0 only in the geodesic sense, so we check determinism + shard identity on
+    a 4K strip instead."""
+    import torch
+    g, rrt, tex = ctx
+    w, h = 3840, 2160
+    cam = rrt.CameraState.default(); fx = rrt.CameraEffects(); prm = rrt.RenderParams(spin=0.9)
+    a = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+    rrt.launch_raymarch(a, w, h, 1.0, cam, tex, fx, prm)
+    torch.cuda.synchronize()
+    img = a.view(h, w, 4)
+    assert bool((img[..., 3] == 255).all())
+    # a 4K strip rendered as a shard equals the same rows of the full frame
+    y0, y1 = 1000, 1064
+    strip = torch.zeros((y1 - y0) * w * 4, dtype=torch.uint8, device="cuda")
+    rrt.launch_raymarch_rows(strip, w, h, y0, y1, 1.0, cam, tex, fx, prm)
+    torch.cuda.synchronize()
+    assert torch.equal(strip, a[(h - y1) * w * 4:(h - y0) * w * 4])
+    # the shadow exists and the disk is bright: coarse sanity of the physical picture
+    lum = img[..., :3].float().mean(dim=2)
+    assert float(lum.max()) > 200 and float((lum < 2).float().mean()) > 0.001

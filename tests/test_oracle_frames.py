@@ -1,0 +1,97 @@
+"""Frame-level checks of the oracle restatement (CPU only).
+
+What pins what:
+  * tests/test_oracle_units.py pins every function the pixel pipeline calls to the reference.
+  * Here: (1) the committed golden frames (regression pins of the restatement, both math modes);
+    (2) the work statistics SURVEY.md 8d measured with the reference's own kernel body
+    (steps/ray, saturated and horizon fractions, noise3D evaluations) -- the only frame-level
+    numbers of the reference that exist; (3) portable-vs-libm closeness.
+"""
+import numpy as np
+import pytest
+
+DEFAULT_CAM = ((0, 10, -60), (0.0, -0.17364804, 0.9848078), (1.0, 0.0, -0.0), (0.0, 0.9848078, 0.17364804))
+
+CASES = {   # == tests/golden/make_golden.py FRAME_CASES
+    "G1": (128, 128, 0.0, 1, 1.0, {}),
+    "G2": (64, 36, 0.9, 0, 1.0, {}),
+    "G3": (64, 36, 0.9, 1, 1.0, {}),
+    "G4": (64, 36, 0.99, 1, 1.0, {}),
+    "G5": (64, 36, 0.9, 1, 12.5, {"use_ca": 1}),
+}
+
+
+def _cam(po, arr):
+    return po.camera(arr[0], arr[1], arr[2], arr[3])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("mode", ["libm", "portable"])
+def test_golden_frames(po, frames_gold, sky, name, mode):
+    w, h, spin, vol, t, fxkw = CASES[name]
+    m = po.MATH_LIBM if mode == "libm" else po.MATH_PORTABLE
+    r = po.render(_cam(po, frames_gold[f"{name}_camera"]), po.default_effects(**fxkw),
+                  po.default_params(spin=spin, volumetrics=vol, math_mode=m), t, w, h, sky,
+                  want=("rgba8", "diag"))
+    assert np.array_equal(r["rgba8"], frames_gold[f"{name}_{mode}_rgba8"])
+    assert np.array_equal(r["steps"], frames_gold[f"{name}_{mode}_steps"].astype(np.int32))
+    assert np.array_equal(r["hit"], frames_gold[f"{name}_{mode}_hit"].astype(np.int32))
+
+
+def test_work_statistics_match_the_survey_probe(po, sky):
+    """SURVEY.md 8d, 128x72, default view, measured on the reference's kernel body:
+    a=0: 1011 steps/ray (min 693, p50 973, p90 1025, p99 2000; 1.6 % at MAX_STEPS), 0.35 % horizon
+    rays, 118.6 noise3D/ray; a=0.9: 1017.5 steps, 119.8 noise3D."""
+    r = po.render(_cam(po, DEFAULT_CAM), po.default_effects(), po.default_params(spin=0.0), 1.0, 128, 72, sky,
+                  want=("diag",))
+    s = r["steps"]
+    assert abs(s.mean() - 1011) < 0.5 and s.min() == 693 and np.median(s) == 973
+    assert np.percentile(s, 90) == 1025 and np.percentile(s, 99) == 2000
+    assert abs((s == 2000).mean() - 0.016) < 0.001
+    assert abs(r["hit"].mean() - 0.0035) < 0.0002
+    assert abs(r["n_noise"].mean() - 118.6) < 0.05
+    r = po.render(_cam(po, DEFAULT_CAM), po.default_effects(), po.default_params(spin=0.9), 1.0, 128, 72, sky,
+                  want=("diag",))
+    assert abs(r["steps"].mean() - 1017.5) < 0.5
+    assert abs(r["n_noise"].mean() - 119.8) < 0.05
+
+
+def test_portable_and_libm_modes_agree_within_tolerance(frames_gold):
+    for name in ("G3", "G4", "G5"):
+        a = frames_gold[f"{name}_libm_ldr"][..., :3]; b = frames_gold[f"{name}_portable_ldr"][..., :3]
+        ok = np.abs(a - b) <= 1e-4 * np.abs(a) + 1e-5
+        assert ok.mean() >= 0.995, name
+        d = np.abs(frames_gold[f"{name}_libm_rgba8"].astype(int) - frames_gold[f"{name}_portable_rgba8"].astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 0.005
+        # geodesics contain no transcendentals: identical step counts in both modes
+        assert np.array_equal(frames_gold[f"{name}_libm_steps"], frames_gold[f"{name}_portable_steps"])
+
+
+def test_volumetrics_switch_keeps_the_march(po, frames_gold):
+    """'skybox only' (G2) takes exactly the steps of the full render (G3): zone step sizes are kept."""
+    assert np.array_equal(frames_gold["G2_libm_steps"], frames_gold["G3_libm_steps"])
+    assert not np.array_equal(frames_gold["G2_libm_rgba8"], frames_gold["G3_libm_rgba8"])
+
+
+def test_subrect_and_stride_render_the_same_pixels(po, sky):
+    cam = _cam(po, DEFAULT_CAM); fx = po.default_effects(); prm = po.default_params(spin=0.9)
+    full = po.render(cam, fx, prm, 1.0, 40, 24, sky)["rgba8"]
+    part = po.render(cam, fx, prm, 1.0, 40, 24, sky, rect=(8, 4, 30, 20))["rgba8"]
+    # rows are bottom-up: image row y is stored at 24-1-y
+    assert np.array_equal(part[24 - 20:24 - 4, 8:30], full[24 - 20:24 - 4, 8:30])
+    assert not part[:24 - 20].any() and not part[:, :8].any()
+    st = po.render(cam, fx, prm, 1.0, 40, 24, sky, stride=(4, 3))["rgba8"]
+    ys = np.arange(0, 24, 3); xs = np.arange(0, 40, 4)
+    assert np.array_equal(st[23 - ys][:, xs], full[23 - ys][:, xs])
+    with pytest.raises(ValueError):
+        po.render(cam, fx, prm, 1.0, 40, 24, sky, rect=(0, 0, 41, 24))
+
+
+def test_alpha_and_row_flip(po, sky):
+    cam = _cam(po, DEFAULT_CAM)
+    r = po.render(cam, po.default_effects(), po.default_params(), 1.0, 32, 32, sky)["rgba8"]
+    assert np.all(r[..., 3] == 255)
+    # the disk is below the image centre line in y (camera pitched down): after the bottom-up flip the
+    # bright rows sit in the upper half of the stored array
+    lum = r[..., :3].astype(int).sum(axis=2).sum(axis=1)
+    assert lum[:16].sum() != lum[16:].sum()

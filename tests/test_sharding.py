@@ -1,0 +1,100 @@
+"""Tile plan / assemble logic and the world_size-2 gather path (gloo, CPU).
+
+The renderer in these tests is the CPU oracle: they check the host-side sharding
+code, not the HIP kernels (those are covered by tests/test_gpu_frames.py).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from relativisticraytracer_amd import sharding as sh
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.mark.parametrize("height,tile_rows,n", [(2160, 16, 8), (90, 8, 3), (90, 7, 2), (5, 16, 4), (64, 64, 1)])
+def test_tile_plan_covers_every_row_once(height, tile_rows, n):
+    seen = np.zeros(height, int)
+    for s in range(n):
+        k_prev = -1
+        for t, y0, rows in sh.tile_plan(height, tile_rows, s, n):
+            assert t % n == s and t > k_prev and rows >= 1 and y0 == t * tile_rows
+            seen[y0:y0 + rows] += 1
+            k_prev = t
+    assert np.all(seen == 1)
+    assert sum(sh.shard_rows(height, tile_rows, s, n) for s in range(n)) == height
+
+
+def test_tile_plan_matches_c_abi():
+    """The C ABI's row count (rrt_tile_shard_rows) and the Python plan agree (no GPU needed)."""
+    import relativisticraytracer_amd as rrt
+    for height, R, n in ((2160, 16, 8), (90, 8, 3), (1, 1, 1), (33, 5, 7)):
+        for s in range(n):
+            assert rrt.tile_shard_rows(height, R, s, n) == sh.shard_rows(height, R, s, n)
+    with pytest.raises(rrt.RRTError):
+        rrt.tile_shard_rows(10, 0, 0, 1)
+    with pytest.raises(ValueError):
+        sh.tile_plan(10, 4, 3, 3)
+
+
+def test_extract_assemble_roundtrip():
+    rng = np.random.default_rng(0)
+    h, w = 45, 13
+    frame = rng.integers(0, 255, (h, w, 4), dtype=np.uint8)
+    for n, R in ((3, 8), (8, 16), (2, 7), (1, 45)):
+        out = np.zeros_like(frame)
+        pad = sh.max_shard_rows(h, R, n)
+        for s in range(n):
+            sh.assemble_numpy(out, sh.extract_numpy(frame, w, h, R, s, n, pad_rows=pad), w, h, R, s, n)
+        assert np.array_equal(out, frame)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from oracle import pyoracle as po
+    from relativisticraytracer_amd.sky import synthetic_sky
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, h, R = 48, 27, 4
+    sky = synthetic_sky(256, 128)
+    cam = po.camera((0, 10, -60), (0, -0.17364804, 0.9848078), (1, 0, 0), (0, 0.9848078, 0.17364804))
+    fx, prm = po.default_effects(), po.default_params(spin=0.9)
+
+    def render(buf):      # oracle stands in for rrt_launch_raymarch_tiles
+        full = np.zeros((h, w, 4), np.uint8)
+        for t, y0, rows in sh.tile_plan(h, R, rank, world):
+            full = po.render(cam, fx, prm, 1.0, w, h, sky, rect=(0, y0, w, y0 + rows), n_threads=1)["rgba8"] | full
+        tiles = sh.extract_numpy(full, w, h, R, rank, world, pad_rows=sh.max_shard_rows(h, R, world))
+        buf.copy_(torch.from_numpy(tiles.reshape(-1)))
+
+    def assemble(frame, buf, shard):
+        f = frame.numpy().reshape(h, w, 4)
+        sh.assemble_numpy(f, buf.numpy().reshape(-1, w, 4), w, h, R, shard, world)
+
+    fs = sh.FrameSharder(w, h, R, rank, world, "cpu", render, assemble)
+    frame = fs.step()
+    if rank == 0:
+        ref = po.render(cam, fx, prm, 1.0, w, h, sky, n_threads=2)["rgba8"]
+        q.put(bool(np.array_equal(frame.numpy().reshape(h, w, 4), ref)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_world2_gloo_matches_single_render():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ok
