@@ -162,6 +162,12 @@ int rrt_unit_math(int fn, int n, const float* d_a, const float* d_b, float* d_ou
 int rrt_unit_sky_sample(int n, const float* d_dir, float off, rrt_sky_t sky, int frac_bits,
                         float* d_out_rgba, void* stream);
 
+/* Self-checks of the march loop's hand-rolled correctly-rounded sqrt / divide against the
+ * hardware IEEE forms.  d_counters: 4 x uint64 on the device, zeroed by the caller;
+ * [0] receives the number of mismatching cases, [1..3] one failing case. */
+int rrt_selfcheck_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* stream);
+int rrt_selfcheck_div(unsigned long long n_cases, uint32_t seed, unsigned long long* d_counters, void* stream);
+
 /* ---- host-side camera helpers (C++ in the reference, src/main.cpp:141-167) ---- */
 int rrt_camera_from_angles(const float pos[3], float yaw_deg, float pitch_deg, rrt_camera* out);
 

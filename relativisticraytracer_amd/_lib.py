@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "lib", "librrt_hip.so")
+LIB_PATH = os.environ.get("RRT_LIB_OVERRIDE") or os.path.join(PKG, "lib", "librrt_hip.so")   # override: dev A/B builds only
 
 RRT_OK = 0
 
@@ -77,6 +77,8 @@ SYMBOLS = [
     ("rrt_unit_redshift", _i, [_i, _vp, _vp, _f, _vp, _vp]),
     ("rrt_unit_math", _i, [_i, _i, _vp, _vp, _vp, _vp]),
     ("rrt_unit_sky_sample", _i, [_i, _vp, _f, _ull, _i, _vp, _vp]),
+    ("rrt_selfcheck_sqrt", _i, [C.c_uint32, C.c_uint32, _vp, _vp]),
+    ("rrt_selfcheck_div", _i, [_ull, C.c_uint32, _vp, _vp]),
     ("rrt_camera_from_angles", _i, [C.POINTER(C.c_float * 3), _f, _f, _cam]),
 ]
 

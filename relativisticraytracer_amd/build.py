@@ -20,8 +20,10 @@ HEADERS = [os.path.join(CSRC, "rrt_device.h"), os.path.join(CSRC, "rrt_math.h"),
            os.path.join(PKG, "..", "include", "rrt.h")]
 
 # -ffp-contract=off: the kernels' arithmetic contract (csrc/rrt_device.h).
+# -fno-slp-vectorize: the SLP vectoriser packs the 3-vector math into v_pk_*_f32 plus a pile of
+# v_mov shuffles; measured 8 % slower than scalar VALU on the march loop (profiles/README.md).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+               "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc_path():

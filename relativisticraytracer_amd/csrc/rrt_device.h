@@ -107,35 +107,93 @@ RRT_DEV float fbm(v3 p) {
 }
 
 /*
+ * Correctly rounded sqrt and divide for the march loop.
+ *
+ * hipcc's own expansions of sqrtf and `/` are correctly rounded too, but carry range
+ * scaling (v_div_scale / v_div_fixup / denormal rescue) that this loop never needs and
+ * that costs ~19-21 issue slots each on gfx950 (profiles/r01_valu_microbench.txt).  The
+ * operands here are tame (r in [1, 1.6e4], quotients normal or exactly zero -- a denormal
+ * quotient would need a ray parallel to its position vector to within 1e-13 rad), so the
+ * bare Newton/Markstein cores are enough; both are checked bit-for-bit against the hardware-IEEE forms over the whole
+ * operand range on the GPU (tests/test_gpu_units.py::test_fast_sqrt_div_*).
+ *
+ *   sqrt_rsq:  y0 = v_rsq_f32(x) (1 ulp); one coupled Goldschmidt step for g ~ sqrt(x),
+ *              h ~ 1/(2 sqrt(x)); final residual correction g + (x - g*g)*h.
+ *   div_seeded: the FMA core of LLVM's f32 fdiv (refine the reciprocal once, then three
+ *              residual corrections), started from a seed accurate to ~2^-20.
+ */
+RRT_DEV void sqrt_rsq(float x, float& root, float& inv_root) {
+    float y0 = __builtin_amdgcn_rsqf(x);
+    float g = x * y0;
+    float h = 0.5f * y0;
+    float r = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, r, g);
+    h = __builtin_fmaf(h, r, h);
+    float d = __builtin_fmaf(-g, g, x);
+    root = __builtin_fmaf(d, h, g);
+    inv_root = h + h;
+}
+
+RRT_DEV float div_seeded(float a, float b, float seed) {
+    float e = __builtin_fmaf(-b, seed, 1.0f);
+    float y = __builtin_fmaf(e, seed, seed);
+    float q = a * y;
+    float r = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, y, q);
+}
+
+/*
  * getGeodesicAcc, geodesics.h:30-45, with SPIN_AXIS = (0,1,0), EVENT_HORIZON = 2:
  *   radial = (-1.5f*2.0f * L2 / (r2*r2*r)) * p        (-1.5f*2.0f folds to -3.0f)
  *   drag   = ((2.0f*a*2.0f) / (r2*r)) * (p.z, 0, -p.x)
  * drag_c = (2.0f*a)*2.0f is computed once on the host (exact scaling).
+ * r2, r and y ~ 1/r come from the caller (the march loop already has them for the
+ * stage-1 point); both reciprocal seeds are powers of y.
  */
 template <bool SPIN>
-RRT_DEV v3 geodesic_acc(v3 p, v3 v, float drag_c) {
-    float r2 = dot(p, p);
-    float r = sqrtf(r2);
+RRT_DEV v3 geodesic_acc_r(v3 p, v3 v, float drag_c, float r2, float r, float y) {
     v3 L = cross(p, v);
     float L2 = dot(L, L);
-    float radial_mag = (-3.0f * L2) / (r2 * r2 * r);
+    float y2 = y * y;
+    float y3 = y2 * y;
+    float d2 = r2 * r;
+    float d1 = (r2 * r2) * r;
+    float radial_mag = div_seeded(-3.0f * L2, d1, y3 * y2);
     v3 acc = mul(p, radial_mag);
     if (SPIN) {
-        float ds = drag_c / (r2 * r);
+        float ds = div_seeded(drag_c, d2, y3);
         acc.x = acc.x + p.z * ds;
         acc.z = acc.z + (-p.x) * ds;
     }
-    if (r < kEventHorizon * 0.5f) acc = mk(0.f, 0.f, 0.f);       /* geodesics.h:33 */
+    if (__builtin_expect(__any(r2 < 1.0f), 0)) {       /* geodesics.h:33: sqrt(r2) < 1  <=>  r2 < 1 */
+        if (r2 < 1.0f) acc = mk(0.f, 0.f, 0.f);
+    }
     return acc;
 }
 
-/* integrate_rk4, integrators.h:23-59 (MASS_POS = 0: the sub() calls are identities). */
 template <bool SPIN>
-RRT_DEV void integrate_rk4(v3& p, v3& v, float h, float drag_c) {
-    const float hh = h * 0.5f;
-    const float h6 = h / 6.0f;
+RRT_DEV v3 geodesic_acc(v3 p, v3 v, float drag_c) {
+    float r2 = dot(p, p);
+    float r, y;
+    sqrt_rsq(r2, r, y);
+    if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {   /* r2 == 0 / tiny: keep the seeds finite */
+        if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
+    }
+    return geodesic_acc_r<SPIN>(p, v, drag_c, r2, r, y);
+}
+
+/*
+ * integrate_rk4, integrators.h:23-59 (MASS_POS = 0: the sub() calls are identities).
+ * `hh` = h*0.5f and `h6` = h/6.0f are passed in (h takes three values in the march).
+ * 2*a + b is evaluated as fma(2, a, b): identical bits, because 2*a is exact.
+ */
+template <bool SPIN>
+RRT_DEV void integrate_rk4_r(v3& p, v3& v, float h, float hh, float h6, float drag_c,
+                             float r2, float r, float y) {
     v3 p0 = p, v0 = v;
-    v3 kv1 = geodesic_acc<SPIN>(p0, v0, drag_c);
+    v3 kv1 = geodesic_acc_r<SPIN>(p0, v0, drag_c, r2, r, y);
     v3 v2 = add(v0, mul(kv1, hh));
     v3 p2 = add(p0, mul(v0, hh));
     v3 kv2 = geodesic_acc<SPIN>(p2, v2, drag_c);
@@ -145,10 +203,26 @@ RRT_DEV void integrate_rk4(v3& p, v3& v, float h, float drag_c) {
     v3 v4 = add(v0, mul(kv3, h));
     v3 p4 = add(p0, mul(v3_, h));
     v3 kv4 = geodesic_acc<SPIN>(p4, v4, drag_c);
-    v3 kv_sum = add(kv1, add(mul(kv2, 2.0f), add(mul(kv3, 2.0f), kv4)));
-    v3 kp_sum = add(v0, add(mul(v2, 2.0f), add(mul(v3_, 2.0f), v4)));
+    v3 kv_sum, kp_sum;
+    kv_sum.x = kv1.x + __builtin_fmaf(2.0f, kv2.x, __builtin_fmaf(2.0f, kv3.x, kv4.x));
+    kv_sum.y = kv1.y + __builtin_fmaf(2.0f, kv2.y, __builtin_fmaf(2.0f, kv3.y, kv4.y));
+    kv_sum.z = kv1.z + __builtin_fmaf(2.0f, kv2.z, __builtin_fmaf(2.0f, kv3.z, kv4.z));
+    kp_sum.x = v0.x + __builtin_fmaf(2.0f, v2.x, __builtin_fmaf(2.0f, v3_.x, v4.x));
+    kp_sum.y = v0.y + __builtin_fmaf(2.0f, v2.y, __builtin_fmaf(2.0f, v3_.y, v4.y));
+    kp_sum.z = v0.z + __builtin_fmaf(2.0f, v2.z, __builtin_fmaf(2.0f, v3_.z, v4.z));
     v = add(v0, mul(kv_sum, h6));
     p = add(p0, mul(kp_sum, h6));
+}
+
+template <bool SPIN>
+RRT_DEV void integrate_rk4(v3& p, v3& v, float h, float drag_c) {
+    float r2 = dot(p, p);
+    float r, y;
+    sqrt_rsq(r2, r, y);
+    if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {
+        if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
+    }
+    integrate_rk4_r<SPIN>(p, v, h, h * 0.5f, h / 6.0f, drag_c, r2, r, y);
 }
 
 /* calculateRedshiftFactor, geodesics.h:11-25 */

@@ -127,22 +127,28 @@ __global__ __launch_bounds__(256) void raymarch_pixels(const FrameArgs a) {
     bool hit = false;
     int i = 0;
 
-    /* raymarcher.cu:41-121 */
+    /* raymarcher.cu:41-121.  The step size takes three values (the `in_cloud_zone` arm of
+     * raymarcher.cu:62 is unreachable: the cloud zone lies inside the disk zone); h*0.5f and
+     * h/6.0f (integrators.h:31,57) are folded per value at compile time. */
+    constexpr float kHVac = kStepSize, kHNear = kStepSize * 0.1f, kHDisk = kStepSize * 0.3f;
     for (; i < a.max_steps; ++i) {
         const v3 rel_p = p;                             /* p - MASS_POS, MASS_POS = 0 */
         const float r2 = dot(rel_p, rel_p);
-        const float r = sqrtf(r2);
+        float r, y;
+        sqrt_rsq(r2, r, y);
+        if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {
+            if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
+        }
         if (r < kEventHorizon * 1.01f) { hit = true; acc.t = 0.0f; break; }
 
-        float h = kStepSize;
         const bool near_bh = r < 18.0f;
         const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
         const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
-        if (near_bh) h *= 0.1f;
-        else if (in_disk) h *= 0.3f;
-        else if (in_cloud) h *= 0.5f;
+        const float h = near_bh ? kHNear : (in_disk ? kHDisk : kHVac);
+        const float hh = near_bh ? kHNear * 0.5f : (in_disk ? kHDisk * 0.5f : kHVac * 0.5f);
+        const float h6 = near_bh ? kHNear / 6.0f : (in_disk ? kHDisk / 6.0f : kHVac / 6.0f);
 
-        integrate_rk4<SPIN>(p, vel, h, a.drag_c);
+        integrate_rk4_r<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, r, y);
 
         if (VOL && (in_disk || in_cloud)) {
             float d_disk = in_disk ? accretion_density<true>(rel_p, a.time) : 0.0f;
@@ -223,7 +229,7 @@ __global__ void k_geodesic_acc(int n, const float* p, const float* v, float spin
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float drag_c = (2.0f * spin) * 2.0f;
-    st3(out, i, geodesic_acc<true>(ld3(p, i), ld3(v, i), drag_c));
+    st3(out, i, geodesic_acc<true>(ld3(p, i), ld3(v, i), drag_c));      /* the march's own code path */
 }
 __global__ void k_rk4(int n, float* p, float* v, const float* h, float spin) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -287,6 +293,52 @@ __global__ void k_sky(int n, const float* dir, float off, SkyTex sky, float* out
     float s[4];
     sample_sky(sky, ld3(dir, i), off, s);
     out[4 * i] = s[0]; out[4 * i + 1] = s[1]; out[4 * i + 2] = s[2]; out[4 * i + 3] = s[3];
+}
+
+/*
+ * Self-checks of the march loop's sqrt/divide cores against the hardware-IEEE forms (sqrtf, `/`).
+ * sqrt: every float whose bit pattern lies in [lo, hi).  div: `n` pseudo-random cases shaped
+ * like the loop's operands: r2 log-uniform in [1, 2^28), seeds from sqrt_rsq(r2), numerators
+ * log-uniform in 2^[-40, 40) with random sign.  counters[0] += mismatches; counters[1..3] keep
+ * one failing case.
+ */
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__global__ void k_selfcheck_sqrt(uint32_t lo, uint32_t hi, unsigned long long* counters) {
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned bad = 0;
+    for (uint64_t b = (uint64_t)lo + idx; b < hi; b += stride) {
+        float x = rrt_u2f((uint32_t)b);
+        float r, y;
+        sqrt_rsq(x, r, y);
+        float want = sqrtf(x);
+        if (rrt_f2u(r) != rrt_f2u(want)) { ++bad; counters[1] = b; }
+    }
+    if (bad) atomicAdd(counters, (unsigned long long)bad);
+}
+__global__ void k_selfcheck_div(unsigned long long n, uint32_t seed, unsigned long long* counters) {
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned bad = 0;
+    for (uint64_t k = idx; k < n; k += stride) {
+        uint32_t h1 = mix32((uint32_t)k * 2654435761u + seed), h2 = mix32(h1 ^ (uint32_t)(k >> 32) ^ 0x9e3779b9u);
+        uint32_t h3 = mix32(h2 + 0x85ebca6bu);
+        float r2 = rrt_u2f(0x3f800000u + (h1 % (28u << 23)));                 /* [1, 2^28) */
+        float num = rrt_u2f(((87u << 23) + (h2 % (80u << 23))) | (h3 & 0x80000000u));   /* +-2^[-40,40) */
+        float c = rrt_u2f(0x3f000000u + (h3 & 0x01ffffffu));                 /* [0.5, 8): drag constants */
+        float r, y;
+        sqrt_rsq(r2, r, y);
+        float y2 = y * y, y3 = y2 * y;
+        float d2 = r2 * r, d1 = (r2 * r2) * r;
+        float q1 = div_seeded(num, d1, y3 * y2), q2 = div_seeded(c, d2, y3);
+        float w1 = num / d1, w2 = c / d2;
+        if (rrt_f2u(q1) != rrt_f2u(w1)) { ++bad; counters[1] = rrt_f2u(num); counters[2] = rrt_f2u(d1); }
+        if (rrt_f2u(q2) != rrt_f2u(w2)) { ++bad; counters[1] = rrt_f2u(c); counters[2] = rrt_f2u(d2); counters[3] = 2; }
+    }
+    if (bad) atomicAdd(counters, (unsigned long long)bad);
 }
 
 /* ------------------------------------------------------------------ host helpers */
@@ -560,6 +612,19 @@ int rrt_unit_sky_sample(int n, const float* dir, float off, rrt_sky_t sky, int f
     if (!so) return RRT_ERR_BAD_HANDLE;
     SkyTex t{so->d_texels, so->w, so->h, frac_bits};
     return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_sky, g, b, 0, s, n, dir, off, t, out); });
+}
+
+int rrt_selfcheck_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* st) {
+    if (!d_counters || lo_bits > hi_bits) return RRT_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(k_selfcheck_sqrt, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(st), lo_bits, hi_bits, d_counters);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+int rrt_selfcheck_div(unsigned long long n, uint32_t seed, unsigned long long* d_counters, void* st) {
+    if (!d_counters) return RRT_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(k_selfcheck_div, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(st), n, seed, d_counters);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
 }
 
 /* CameraController::getCUDAStateFrom, reference src/main.cpp:141-167 (host C++ there too).

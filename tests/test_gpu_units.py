@@ -134,6 +134,29 @@ def test_sky_sampler_bitexact(g, po, sky):
     tex.destroy()
 
 
+def test_fast_sqrt_is_correctly_rounded_everywhere_it_is_used(g):
+    """sqrt_rsq (rsq + Newton + residual fix-up) == IEEE sqrtf for EVERY float in [1, 2^64)."""
+    import ctypes as C
+    import torch
+    from relativisticraytracer_amd import _lib
+    cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
+    lo, hi = 0x3f800000, 0x3f800000 + (64 << 23)
+    _lib.check(_lib.load().rrt_selfcheck_sqrt(lo, hi, C.c_void_p(cnt.data_ptr()), None), "selfcheck_sqrt")
+    torch.cuda.synchronize()
+    assert int(cnt[0]) == 0, f"{int(cnt[0])} mismatches, e.g. bits {int(cnt[1]):#x}"
+
+
+def test_fast_divide_is_correctly_rounded_on_march_operands(g):
+    """div_seeded (Markstein core seeded from powers of 1/r) == IEEE `/` on 2^32 march-shaped cases."""
+    import ctypes as C
+    import torch
+    from relativisticraytracer_amd import _lib
+    cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
+    _lib.check(_lib.load().rrt_selfcheck_div(1 << 32, 12345, C.c_void_p(cnt.data_ptr()), None), "selfcheck_div")
+    torch.cuda.synchronize()
+    assert int(cnt[0]) == 0, f"{int(cnt[0])} mismatches, e.g. {int(cnt[1]):#x} / {int(cnt[2]):#x}"
+
+
 def test_unit_kernels_empty_and_bad_args(g):
     import torch
     from relativisticraytracer_amd import _lib
