@@ -1,0 +1,36 @@
+"""dev tool: condense gpurun_out/prof_<tag>/ into profiles/<tag>_*.{csv,json} (run in the container)."""
+import csv, glob, json, os, sys
+tag = sys.argv[1]
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+out = {"tag": tag}
+ks = glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True)
+if ks:
+    rows = list(csv.DictReader(open(ks[0])))
+    with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
+        f.write(open(ks[0]).read())
+    for r in rows:
+        if "raymarch" in r["Name"]:
+            out["kernel"] = r["Name"]; out["calls"] = int(r["Calls"]); out["avg_ms"] = float(r["AverageNs"]) / 1e6
+kt = glob.glob(f"{src}/trace/**/*kernel_trace.csv", recursive=True)
+if kt:
+    for r in csv.DictReader(open(kt[0])):
+        if "raymarch" in r["Kernel_Name"]:
+            out["vgpr"] = int(r["VGPR_Count"]); out["sgpr"] = int(r["SGPR_Count"]); out["lds"] = int(r["LDS_Block_Size"])
+            out["scratch"] = int(r["Scratch_Size"]); out["grid"] = [int(r["Grid_Size_X"]), int(r["Grid_Size_Y"])]
+            break
+for name in ("fetch", "write", "sq"):
+    cs = glob.glob(f"{src}/pmc_{name}/**/*counter_collection.csv", recursive=True)
+    if not cs:
+        continue
+    acc = {}
+    n = {}
+    for r in csv.DictReader(open(cs[0])):
+        if "raymarch" not in r["Kernel_Name"]:
+            continue
+        acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        n[r["Counter_Name"]] = n.get(r["Counter_Name"], 0) + 1
+    for k in acc:
+        out[k + "_per_launch"] = acc[k] / n[k]
+json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
