@@ -79,8 +79,16 @@ typedef struct rrt_params {
                                 zone-dependent step sizes unchanged        */
     int32_t sky_frac_bits;   /* bilinear weight bits of the sky sampler:
                                 8 = CUDA-texture-like (default), 0 = exact  */
-    int32_t reserved[4];     /* must be 0 */
+    int32_t arith_mode;      /* RRT_ARITH_STRICT (default): every operation rounded as the
+                                reference source writes it -- the parity path.
+                                RRT_ARITH_FAST: fused multiply-adds and 1-ulp reciprocal
+                                square roots in the geodesic integrator; NOT bit-comparable
+                                with the oracle                      */
+    int32_t reserved[3];     /* must be 0 */
 } rrt_params;
+
+#define RRT_ARITH_STRICT 0
+#define RRT_ARITH_FAST 1
 
 /* Opaque sky-texture handle; stands in for cudaTextureObject_t
  * (`unsigned long long`, reference src/main.cpp:231-263). */
@@ -168,8 +176,21 @@ int rrt_unit_sky_sample(int n, const float* d_dir, float off, rrt_sky_t sky, int
 int rrt_selfcheck_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* stream);
 int rrt_selfcheck_div(unsigned long long n_cases, uint32_t seed, unsigned long long* d_counters, void* stream);
 
-/* ---- host-side camera helpers (C++ in the reference, src/main.cpp:141-167) ---- */
+/* ---- host-side camera helpers (host C++ in the reference too) ---- */
+/* CameraController::getCUDAStateFrom, src/main.cpp:141-167 (degrees; note its 3.14159f) */
 int rrt_camera_from_angles(const float pos[3], float yaw_deg, float pitch_deg, rrt_camera* out);
+/* catmull_rom / lerp_angle, src/camera_paths.cpp:6-29 */
+int rrt_catmull_rom(const float p0[3], const float p1[3], const float p2[3], const float p3[3], float t, float out[3]);
+int rrt_lerp_angle(float a, float b, float t, float* out);
+/* the three built-in keyframe paths, src/camera_paths.cpp:31-73 (0 "Gargantua Fly-By",
+ * 1 "Event Horizon Focus", 2 "Horizon Skimmer"); keyframes are 6 floats: time, x, y, z, yaw, pitch */
+int rrt_path_count(void);
+int rrt_path_info(int path, const char** name, int* n_keys, float* t_end);
+int rrt_path_keyframes(int path, float* out6, int cap_keys);
+/* PathController::getInterpolatedState, src/main.cpp:176-203 */
+int rrt_path_camera_at(int path, float path_time, rrt_camera* out);
+/* recording clock of the main loop, src/main.cpp:511-516: times seen by 1-based frame k */
+int rrt_recording_clock(int frame_k, int fps, float* sim_time, float* path_time);
 
 #ifdef __cplusplus
 }

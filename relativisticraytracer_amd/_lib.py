@@ -38,7 +38,7 @@ class rrt_effects(C.Structure):
 
 class rrt_params(C.Structure):
     _fields_ = [("spin", C.c_float), ("max_steps", C.c_int32), ("volumetrics", C.c_int32),
-                ("sky_frac_bits", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("sky_frac_bits", C.c_int32), ("arith_mode", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class rrt_debug_outputs(C.Structure):
@@ -80,6 +80,13 @@ SYMBOLS = [
     ("rrt_selfcheck_sqrt", _i, [C.c_uint32, C.c_uint32, _vp, _vp]),
     ("rrt_selfcheck_div", _i, [_ull, C.c_uint32, _vp, _vp]),
     ("rrt_camera_from_angles", _i, [C.POINTER(C.c_float * 3), _f, _f, _cam]),
+    ("rrt_catmull_rom", _i, [C.POINTER(C.c_float * 3)] * 4 + [_f, C.POINTER(C.c_float * 3)]),
+    ("rrt_lerp_angle", _i, [_f, _f, _f, C.POINTER(_f)]),
+    ("rrt_path_count", _i, []),
+    ("rrt_path_info", _i, [_i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_f)]),
+    ("rrt_path_keyframes", _i, [_i, _vp, _i]),
+    ("rrt_path_camera_at", _i, [_i, _f, _cam]),
+    ("rrt_recording_clock", _i, [_i, _i, C.POINTER(_f), C.POINTER(_f)]),
 ]
 
 _lib = None

@@ -225,6 +225,61 @@ RRT_DEV void integrate_rk4(v3& p, v3& v, float h, float drag_c) {
     integrate_rk4_r<SPIN>(p, v, h, h * 0.5f, h / 6.0f, drag_c, r2, r, y);
 }
 
+/*
+ * FAST arithmetic mode (rrt_params.arith_mode = RRT_ARITH_FAST; NOT the parity path).
+ * Same equations (geodesics.h:30-45, integrators.h:23-59) evaluated the way a GPU compiler with
+ * contraction would: fused multiply-adds, 1/r from v_rsq_f32 (1 ulp) instead of correctly rounded
+ * sqrt and divides.  Every step is perturbed at the 1e-7 relative level, so frames differ from the
+ * strict path / the oracle by rounding noise that near-critical rays amplify; the measured
+ * deviation is reported by tests/test_gpu_frames.py::test_fast_mode_* and DESIGN.md.
+ */
+template <bool SPIN>
+RRT_DEV v3 geodesic_acc_fast(v3 p, v3 v, float drag_c, float r2, float y) {
+    v3 L = mk(__builtin_fmaf(p.y, v.z, -(p.z * v.y)), __builtin_fmaf(p.z, v.x, -(p.x * v.z)),
+              __builtin_fmaf(p.x, v.y, -(p.y * v.x)));
+    float L2 = __builtin_fmaf(L.z, L.z, __builtin_fmaf(L.y, L.y, L.x * L.x));
+    float y2 = y * y;
+    float y3 = y2 * y;
+    float mag = (-3.0f * L2) * (y3 * y2);
+    v3 acc = mul(p, mag);
+    if (SPIN) {
+        float ds = drag_c * y3;
+        acc.x = __builtin_fmaf(p.z, ds, acc.x);
+        acc.z = __builtin_fmaf(-p.x, ds, acc.z);
+    }
+    if (__builtin_expect(__any(r2 < 1.0f), 0)) {
+        if (r2 < 1.0f) acc = mk(0.f, 0.f, 0.f);
+    }
+    return acc;
+}
+
+RRT_DEV float dot_fma(v3 a, v3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+RRT_DEV v3 axpy(v3 x, float a, v3 y) {       /* a*x + y, fused */
+    return mk(__builtin_fmaf(x.x, a, y.x), __builtin_fmaf(x.y, a, y.y), __builtin_fmaf(x.z, a, y.z));
+}
+
+template <bool SPIN>
+RRT_DEV void integrate_rk4_fast(v3& p, v3& v, float h, float hh, float h6, float drag_c, float r2, float y) {
+    v3 p0 = p, v0 = v;
+    v3 kv1 = geodesic_acc_fast<SPIN>(p0, v0, drag_c, r2, y);
+    v3 v2 = axpy(kv1, hh, v0);
+    v3 p2 = axpy(v0, hh, p0);
+    float r2b = dot_fma(p2, p2);
+    v3 kv2 = geodesic_acc_fast<SPIN>(p2, v2, drag_c, r2b, __builtin_amdgcn_rsqf(r2b));
+    v3 v3_ = axpy(kv2, hh, v0);
+    v3 p3 = axpy(v2, hh, p0);
+    float r2c = dot_fma(p3, p3);
+    v3 kv3 = geodesic_acc_fast<SPIN>(p3, v3_, drag_c, r2c, __builtin_amdgcn_rsqf(r2c));
+    v3 v4 = axpy(kv3, h, v0);
+    v3 p4 = axpy(v3_, h, p0);
+    float r2d = dot_fma(p4, p4);
+    v3 kv4 = geodesic_acc_fast<SPIN>(p4, v4, drag_c, r2d, __builtin_amdgcn_rsqf(r2d));
+    v3 kv_sum = add(kv1, axpy(kv2, 2.0f, axpy(kv3, 2.0f, kv4)));
+    v3 kp_sum = add(v0, axpy(v2, 2.0f, axpy(v3_, 2.0f, v4)));
+    v = axpy(kv_sum, h6, v0);
+    p = axpy(kp_sum, h6, p0);
+}
+
 /* calculateRedshiftFactor, geodesics.h:11-25 */
 RRT_DEV float redshift_factor(v3 p, v3 ray_vel, float spin) {
     float r = length(p);

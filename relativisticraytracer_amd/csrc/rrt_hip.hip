@@ -94,7 +94,7 @@ __device__ __forceinline__ bool map_row(const RowMap& m, int height, int lr, int
  * block as four 8x8 wave tiles so that the 64 rays of a wavefront stay
  * spatially coherent (similar step counts, similar zone entry).
  */
-template <bool SPIN, bool VOL, bool DEBUG>
+template <bool SPIN, bool VOL, bool DEBUG, bool FAST>
 __global__ __launch_bounds__(256) void raymarch_pixels(const FrameArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
@@ -133,11 +133,20 @@ __global__ __launch_bounds__(256) void raymarch_pixels(const FrameArgs a) {
     constexpr float kHVac = kStepSize, kHNear = kStepSize * 0.1f, kHDisk = kStepSize * 0.3f;
     for (; i < a.max_steps; ++i) {
         const v3 rel_p = p;                             /* p - MASS_POS, MASS_POS = 0 */
-        const float r2 = dot(rel_p, rel_p);
-        float r, y;
-        sqrt_rsq(r2, r, y);
-        if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {
-            if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
+        float r2, r, y;
+        if (FAST) {
+            r2 = dot_fma(rel_p, rel_p);
+            y = __builtin_amdgcn_rsqf(r2);
+            r = r2 * y;
+            if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {
+                if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
+            }
+        } else {
+            r2 = dot(rel_p, rel_p);
+            sqrt_rsq(r2, r, y);
+            if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {
+                if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
+            }
         }
         if (r < kEventHorizon * 1.01f) { hit = true; acc.t = 0.0f; break; }
 
@@ -148,7 +157,8 @@ __global__ __launch_bounds__(256) void raymarch_pixels(const FrameArgs a) {
         const float hh = near_bh ? kHNear * 0.5f : (in_disk ? kHDisk * 0.5f : kHVac * 0.5f);
         const float h6 = near_bh ? kHNear / 6.0f : (in_disk ? kHDisk / 6.0f : kHVac / 6.0f);
 
-        integrate_rk4_r<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, r, y);
+        if (FAST) integrate_rk4_fast<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, y);
+        else integrate_rk4_r<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, r, y);
 
         if (VOL && (in_disk || in_cloud)) {
             float d_disk = in_disk ? accretion_density<true>(rel_p, a.time) : 0.0f;
@@ -349,13 +359,14 @@ int check_common(const void* out, int width, int height, const rrt_camera* cam, 
     if (prm) {
         if (prm->max_steps < 0 || prm->sky_frac_bits < 0 || prm->sky_frac_bits > 16) return RRT_ERR_INVALID_ARGUMENT;
         if (!(prm->spin == prm->spin)) return RRT_ERR_INVALID_ARGUMENT;
-        for (int k = 0; k < 4; ++k)
+        if (prm->arith_mode != RRT_ARITH_STRICT && prm->arith_mode != RRT_ARITH_FAST) return RRT_ERR_INVALID_ARGUMENT;
+        for (int k = 0; k < 3; ++k)
             if (prm->reserved[k] != 0) return RRT_ERR_INVALID_ARGUMENT;
     }
     return RRT_OK;
 }
 
-int fill_args(FrameArgs& a, bool& vol, void* out, int width, int height, float time, const rrt_camera* cam,
+int fill_args(FrameArgs& a, bool& vol, bool& fast, void* out, int width, int height, float time, const rrt_camera* cam,
               rrt_sky_t sky, const rrt_effects* fx, const rrt_params* prm_in) {
     rrt_params prm;
     if (prm_in) prm = *prm_in; else rrt_params_default(&prm);
@@ -374,15 +385,17 @@ int fill_args(FrameArgs& a, bool& vol, void* out, int width, int height, float t
     a.max_steps = prm.max_steps;
     memset(&a.dbg, 0, sizeof(a.dbg));
     vol = prm.volumetrics != 0;
+    fast = prm.arith_mode == RRT_ARITH_FAST;
     return RRT_OK;
 }
 
-int launch(const FrameArgs& a, bool vol, bool debug, hipStream_t st) {
+int launch(const FrameArgs& a, bool vol, bool debug, bool fast, hipStream_t st) {
     dim3 block(256);
     dim3 grid((a.width + 15) / 16, (a.rows.n_local_rows + 15) / 16);
     if (grid.y == 0) return RRT_OK;
     const bool spin = a.spin != 0.0f;
-#define RRT_LAUNCH(S, V, D) hipLaunchKernelGGL((raymarch_pixels<S, V, D>), grid, block, 0, st, a)
+#define RRT_LAUNCH(S, V, D) do { if (fast) hipLaunchKernelGGL((raymarch_pixels<S, V, D, true>), grid, block, 0, st, a); \
+                                 else hipLaunchKernelGGL((raymarch_pixels<S, V, D, false>), grid, block, 0, st, a); } while (0)
     if (debug) {
         if (spin) { if (vol) RRT_LAUNCH(true, true, true); else RRT_LAUNCH(true, false, true); }
         else      { if (vol) RRT_LAUNCH(false, true, true); else RRT_LAUNCH(false, false, true); }
@@ -505,11 +518,11 @@ int rrt_launch_raymarch_rows(void* d_out_rows, int width, int height, int y0, in
     if (rc) return rc;
     if (y0 < 0 || y1 > height || y0 > y1) return RRT_ERR_INVALID_ARGUMENT;
     FrameArgs a;
-    bool vol;
-    rc = fill_args(a, vol, d_out_rows, width, height, time, cam, sky, fx, prm);
+    bool vol, fast;
+    rc = fill_args(a, vol, fast, d_out_rows, width, height, time, cam, sky, fx, prm);
     if (rc) return rc;
     a.rows = RowMap{y1 - y0, y0, y1 - y0 > 0 ? y1 - y0 : 1, 0, 1};
-    return launch(a, vol, false, static_cast<hipStream_t>(stream));
+    return launch(a, vol, false, fast, static_cast<hipStream_t>(stream));
 }
 
 int rrt_launch_raymarch(void* d_out_rgba8, int width, int height, float time, const rrt_camera* cam,
@@ -523,12 +536,12 @@ int rrt_launch_raymarch_ex(void* d_out_rgba8, int width, int height, float time,
     int rc = check_common(d_out_rgba8, width, height, cam, fx, prm);
     if (rc) return rc;
     FrameArgs a;
-    bool vol;
-    rc = fill_args(a, vol, d_out_rgba8, width, height, time, cam, sky, fx, prm);
+    bool vol, fast;
+    rc = fill_args(a, vol, fast, d_out_rgba8, width, height, time, cam, sky, fx, prm);
     if (rc) return rc;
     a.rows = RowMap{height, 0, height, 0, 1};
     if (dbg) a.dbg = *dbg;
-    return launch(a, vol, dbg != nullptr, static_cast<hipStream_t>(stream));
+    return launch(a, vol, dbg != nullptr, fast, static_cast<hipStream_t>(stream));
 }
 
 int rrt_tile_shard_rows(int height, int tile_rows, int shard, int n_shards, int* rows) {
@@ -545,11 +558,11 @@ int rrt_launch_raymarch_tiles(void* d_out_tiles, int width, int height, int tile
     if (rc) return rc;
     if (tile_rows <= 0 || n_shards <= 0 || shard < 0 || shard >= n_shards) return RRT_ERR_INVALID_ARGUMENT;
     FrameArgs a;
-    bool vol;
-    rc = fill_args(a, vol, d_out_tiles, width, height, time, cam, sky, fx, prm);
+    bool vol, fast;
+    rc = fill_args(a, vol, fast, d_out_tiles, width, height, time, cam, sky, fx, prm);
     if (rc) return rc;
     a.rows = RowMap{shard_rows(height, tile_rows, shard, n_shards), 0, tile_rows, shard, n_shards};
-    return launch(a, vol, false, static_cast<hipStream_t>(stream));
+    return launch(a, vol, false, fast, static_cast<hipStream_t>(stream));
 }
 
 int rrt_assemble_tiles(void* d_frame, const void* d_tiles, int width, int height, int tile_rows, int shard,
@@ -624,6 +637,115 @@ int rrt_selfcheck_div(unsigned long long n, uint32_t seed, unsigned long long* d
     if (!d_counters) return RRT_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(k_selfcheck_div, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(st), n, seed, d_counters);
     RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+
+/* ---------------------------------------------------------------- camera paths (host)
+ * Reference: catmull_rom / lerp_angle / initDefaultPaths, src/camera_paths.cpp:6-73;
+ * PathController::getInterpolatedState, src/main.cpp:176-203; fixed recording clock,
+ * src/main.cpp:511-516.  The keyframe tables are data and keep the reference's values. */
+}  // extern "C"  (re-opened below)
+
+namespace {
+struct Key { float time, x, y, z, yaw, pitch; };
+struct Path { const char* name; int n; Key keys[6]; };
+const Path kPaths[3] = {
+    {"Gargantua Fly-By", 5, {{0.0f, 0.0f, 15.0f, -80.0f, 0.0f, -10.6f},
+                             {6.0f, 15.0f, 3.0f, -30.0f, -26.6f, -5.1f},
+                             {12.0f, 35.0f, 0.8f, 10.0f, -106.0f, -1.2f},
+                             {18.0f, 5.0f, 1.5f, 50.0f, -174.3f, -1.7f},
+                             {25.0f, -20.0f, 12.0f, 70.0f, -196.0f, -9.3f}}},
+    {"Event Horizon Focus", 5, {{0.0f, 40.0f, 2.0f, 0.0f, -90.0f, 0.0f},
+                                {8.0f, 0.0f, 5.0f, 40.0f, -180.0f, -5.0f},
+                                {16.0f, -40.0f, 2.0f, 0.0f, -270.0f, 0.0f},
+                                {24.0f, 0.0f, -5.0f, -40.0f, -360.0f, 5.0f},
+                                {32.0f, 40.0f, 2.0f, 0.0f, -450.0f, 0.0f}}},
+    {"Horizon Skimmer", 6, {{0.0f, 0.0f, 10.0f, -60.0f, 0.0f, -9.5f},
+                            {8.0f, 15.0f, 2.0f, -15.0f, -45.0f, -4.7f},
+                            {14.0f, 4.2f, 0.6f, 4.2f, -90.0f, -5.7f},
+                            {20.0f, -20.0f, 8.0f, -20.0f, -225.0f, -20.0f},
+                            {26.0f, -20.0f, 8.0f, -20.0f, 20.0f, -10.0f},
+                            {29.0f, -30.0f, 2.0f, -30.0f, 45.0f, -2.7f}}},
+};
+
+float catmull_1d(float a, float b, float c, float d, float t, float t2, float t3) {   /* camera_paths.cpp:10-15 */
+    return 0.5f * ((2.0f * b) + (-a + c) * t + (2.0f * a - 5.0f * b + 4.0f * c - d) * t2 +
+                   (-a + 3.0f * b - 3.0f * c + d) * t3);
+}
+float lerp_angle_f(float a, float b, float t) {                                       /* camera_paths.cpp:25-29 */
+    float diff = fmodf(b - a + 180.0f, 360.0f) - 180.0f;
+    if (diff < -180.0f) diff += 360.0f;
+    return a + diff * t;
+}
+}  // namespace
+
+extern "C" {
+
+int rrt_catmull_rom(const float p0[3], const float p1[3], const float p2[3], const float p3[3], float t,
+                    float out[3]) {
+    if (!p0 || !p1 || !p2 || !p3 || !out) return RRT_ERR_INVALID_ARGUMENT;
+    float t2 = t * t, t3 = t2 * t;
+    for (int k = 0; k < 3; ++k) out[k] = catmull_1d(p0[k], p1[k], p2[k], p3[k], t, t2, t3);
+    return RRT_OK;
+}
+
+int rrt_lerp_angle(float a, float b, float t, float* out) {
+    if (!out) return RRT_ERR_INVALID_ARGUMENT;
+    *out = lerp_angle_f(a, b, t);
+    return RRT_OK;
+}
+
+int rrt_path_count(void) { return 3; }
+
+int rrt_path_info(int idx, const char** name, int* n_keys, float* t_end) {
+    if (idx < 0 || idx >= 3) return RRT_ERR_INVALID_ARGUMENT;
+    if (name) *name = kPaths[idx].name;
+    if (n_keys) *n_keys = kPaths[idx].n;
+    if (t_end) *t_end = kPaths[idx].keys[kPaths[idx].n - 1].time;
+    return RRT_OK;
+}
+
+int rrt_path_keyframes(int idx, float* out6, int cap_keys) {
+    if (idx < 0 || idx >= 3 || !out6 || cap_keys < kPaths[idx].n) return RRT_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < kPaths[idx].n; ++i) memcpy(out6 + 6 * i, &kPaths[idx].keys[i], 6 * sizeof(float));
+    return RRT_OK;
+}
+
+/* PathController::getInterpolatedState, src/main.cpp:176-203 */
+int rrt_path_camera_at(int idx, float t, rrt_camera* out) {
+    if (idx < 0 || idx >= 3 || !out) return RRT_ERR_INVALID_ARGUMENT;
+    const Path& P = kPaths[idx];
+    const Key* k = P.keys;
+    const int n = P.n;
+    auto from_key = [&](const Key& q) { float pos[3] = {q.x, q.y, q.z}; return rrt_camera_from_angles(pos, q.yaw, q.pitch, out); };
+    if (t <= k[0].time) return from_key(k[0]);
+    if (t >= k[n - 1].time) return from_key(k[n - 1]);
+    for (int i = 0; i < n - 1; ++i) {
+        if (t >= k[i].time && t <= k[i + 1].time) {
+            float factor = (t - k[i].time) / (k[i + 1].time - k[i].time);
+            int i0 = i - 1 > 0 ? i - 1 : 0, i1 = i, i2 = i + 1, i3 = i + 2 < n - 1 ? i + 2 : n - 1;
+            float a[3] = {k[i0].x, k[i0].y, k[i0].z}, b[3] = {k[i1].x, k[i1].y, k[i1].z};
+            float c[3] = {k[i2].x, k[i2].y, k[i2].z}, d[3] = {k[i3].x, k[i3].y, k[i3].z};
+            float pos[3];
+            rrt_catmull_rom(a, b, c, d, factor, pos);
+            float yaw = lerp_angle_f(k[i1].yaw, k[i2].yaw, factor);
+            float pitch = lerp_angle_f(k[i1].pitch, k[i2].pitch, factor);
+            return rrt_camera_from_angles(pos, yaw, pitch, out);
+        }
+    }
+    return from_key(k[n - 1]);
+}
+
+/* The recording clock of the reference's main loop (src/main.cpp:511-516): dt = 1.0f / fps,
+ * simTime and pathTime are float accumulators advanced BEFORE each render, so frame k
+ * (1-based) is rendered at sum_{1..k} dt evaluated in binary32. */
+int rrt_recording_clock(int frame_k, int fps, float* sim_time, float* path_time) {
+    if (frame_k < 0 || fps <= 0) return RRT_ERR_INVALID_ARGUMENT;
+    const float dt = 1.0f / (float)fps;
+    float s = 0.0f, p = 0.0f;
+    for (int i = 0; i < frame_k; ++i) { s += dt; p += dt; }
+    if (sim_time) *sim_time = s;
+    if (path_time) *path_time = p;
     return RRT_OK;
 }
 

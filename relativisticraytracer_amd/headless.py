@@ -1,0 +1,98 @@
+"""Headless frame driver: the reference's main loop (src/main.cpp:505-529) without a window.
+
+    python -m relativisticraytracer_amd.headless --width 1920 --height 1080 --spin 0.9 \\
+           --path 0 --frames 300 [--out frames.rgba | --out ppm_dir/] [--all-effects]
+    python -m torch.distributed.run --nproc-per-node 8 -m relativisticraytracer_amd.headless ...
+
+Per frame k = 1..N it does what `main()` does while recording: advance the fixed 1/24 s clock
+(float accumulators, main.cpp:511-516), take the camera from the active path
+(getInterpolatedState, :176-203) or the fixed start-up camera, render (launch_raymarch, :467),
+hand the pixels to the sink (captureFrame, :85-97).  With several ranks every frame is
+row-tile sharded and gathered to rank 0 (sharding.FrameSharder).  Prints one JSON line of metrics.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="relativisticraytracer_amd.headless")
+    ap.add_argument("--width", type=int, default=1000)          # WINDOW_WIDTH, config.h:7
+    ap.add_argument("--height", type=int, default=700)          # WINDOW_HEIGHT, config.h:8
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--fps", type=int, default=24)              # RECORDING_FPS, config.h:9
+    ap.add_argument("--spin", type=float, default=0.0)          # SPIN_A, config.h:21
+    ap.add_argument("--path", type=int, default=-1, help="built-in camera path 0..2; -1 = fixed start-up camera")
+    ap.add_argument("--no-volumetrics", action="store_true")
+    ap.add_argument("--fast", action="store_true", help="RRT_ARITH_FAST (not the parity path)")
+    ap.add_argument("--all-effects", action="store_true", help="also enable chromatic aberration (key C)")
+    ap.add_argument("--sky", default=None, help="equirectangular image file; default: synthetic sky, seed 1")
+    ap.add_argument("--tile-rows", type=int, default=16)
+    ap.add_argument("--out", default=None, help="x.rgba (raw, bottom-up) | dir/ (PPM per frame) | x.mp4 (needs ffmpeg)")
+    args = ap.parse_args(argv)
+
+    import numpy as np
+    import torch
+    import relativisticraytracer_amd as rrt
+    from relativisticraytracer_amd import camera_paths, sharding, sinks
+    from relativisticraytracer_amd.sky import load_sky, synthetic_sky
+
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("the headless driver needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    w, h = args.width, args.height
+    tex = rrt.SkyTexture(load_sky(args.sky) if args.sky else synthetic_sky())
+    fx = rrt.CameraEffects(useChromaticAberration=bool(args.all_effects))
+    prm = rrt.RenderParams(spin=args.spin, volumetrics=0 if args.no_volumetrics else 1,
+                           arith_mode=1 if args.fast else 0)
+    path = camera_paths.CameraPath(args.path) if args.path >= 0 else None
+    state = {"t": 0.0, "cam": rrt.CameraState.default()}
+
+    def render(buf):
+        rrt.launch_raymarch_tiles(buf, w, h, args.tile_rows, rank, world, state["t"], state["cam"], tex, fx, prm)
+
+    def assemble(frame, buf, shard):
+        rrt.assemble_tiles(frame, buf, w, h, args.tile_rows, shard, world)
+
+    fs = sharding.FrameSharder(w, h, args.tile_rows, rank, world, dev, render, assemble)
+    sink = sinks.open_sink(args.out, w, h, args.fps) if rank == 0 else None
+    host = torch.empty(h * w * 4, dtype=torch.uint8, pin_memory=True) if sink else None
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(1, args.frames + 1):
+        sim_t, path_t = camera_paths.recording_clock(k, args.fps)
+        state["t"] = sim_t
+        if path is not None:
+            state["cam"] = path.camera_at(path_t)
+        frame = fs.step()
+        if sink:
+            host.copy_(frame, non_blocking=False)
+            sink.write(host.numpy().reshape(h, w, 4))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        if sink:
+            sink.close()
+        print(json.dumps({"frames": args.frames, "width": w, "height": h, "n_gpus": world, "seconds": round(dt, 4),
+                          "fps": round(args.frames / dt, 3), "Mrays_per_s": round(args.frames * w * h / dt / 1e6, 3),
+                          "path": path.name if path else None, "spin": args.spin,
+                          "arith_mode": "fast" if args.fast else "strict", "sink": args.out}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    tex.destroy()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,3 +36,11 @@ def synthetic_sky(width=2048, height=1024, seed=1):
     out[..., 2] = np.clip(b, 0, 255)
     out[..., 3] = 255
     return out
+
+
+def load_sky(path):
+    """Decode an equirectangular image to (H, W, 4) uint8 RGBA, row 0 = top -- what the reference gets
+    from stbi_load(..., 4) (src/main.cpp:240).  Decoders differ by +-1/255 on JPEGs; this uses PIL."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.ascontiguousarray(np.asarray(im.convert("RGBA"), dtype=np.uint8))

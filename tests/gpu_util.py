@@ -30,12 +30,13 @@ def unit(name, *args):
     _lib.check(getattr(lib, "rrt_unit_" + name)(*conv), "rrt_unit_" + name)
 
 
-def render_gpu(w, h, spin, vol, cam, time, sky_tex, fx=None, debug=True, max_steps=2000, frac_bits=8):
+def render_gpu(w, h, spin, vol, cam, time, sky_tex, fx=None, debug=True, max_steps=2000, frac_bits=8, arith_mode=0):
     """Full-frame render through rrt_launch_raymarch(_ex); returns numpy arrays."""
     import torch
     import relativisticraytracer_amd as rrt
     fx = fx or rrt.CameraEffects()
-    prm = rrt.RenderParams(spin=spin, volumetrics=vol, max_steps=max_steps, sky_frac_bits=frac_bits)
+    prm = rrt.RenderParams(spin=spin, volumetrics=vol, max_steps=max_steps, sky_frac_bits=frac_bits,
+                           arith_mode=arith_mode)
     out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
     res = {}
     if debug:

@@ -1,0 +1,64 @@
+"""Headless driver + sinks (rows f3/f4 of SURVEY.md 8)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_sinks_roundtrip(tmp_path):
+    from relativisticraytracer_amd import sinks
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 255, (5, 7, 4), dtype=np.uint8) for _ in range(3)]
+    raw = sinks.open_sink(str(tmp_path / "f.rgba"), 7, 5)
+    ppm = sinks.open_sink(str(tmp_path / "ppm") + "/", 7, 5)
+    for f in frames:
+        raw.write(f); ppm.write(f)
+    raw.close(); ppm.close()
+    data = np.fromfile(tmp_path / "f.rgba", np.uint8).reshape(3, 5, 7, 4)
+    assert np.array_equal(data, np.stack(frames))                       # raw keeps the bottom-up bytes
+    blob = open(tmp_path / "ppm" / "frame_00002.ppm", "rb").read()
+    assert blob.startswith(b"P6\n7 5\n255\n")
+    rgb = np.frombuffer(blob[len(b"P6\n7 5\n255\n"):], np.uint8).reshape(5, 7, 3)
+    assert np.array_equal(rgb, frames[1][::-1, :, :3])                  # PPM is flipped to top-down
+    with pytest.raises(ValueError):
+        raw2 = sinks.RawSink(str(tmp_path / "g.rgba"), 7, 5); raw2.write(np.zeros((4, 7, 4), np.uint8))
+    assert sinks.open_sink(None, 7, 5) is None
+
+
+def test_load_sky_matches_pil(tmp_path):
+    from PIL import Image
+    from relativisticraytracer_amd.sky import load_sky, synthetic_sky
+    s = synthetic_sky(64, 32)
+    Image.fromarray(s[..., :3]).save(tmp_path / "s.png")
+    got = load_sky(str(tmp_path / "s.png"))
+    assert got.shape == (32, 64, 4) and np.array_equal(got[..., :3], s[..., :3]) and np.all(got[..., 3] == 255)
+
+
+@pytest.mark.gpu
+def test_headless_path_playback_equals_manual_frames(tmp_path):
+    """3 frames of path 0: the driver's raw output == frames rendered by hand with the same clock/camera."""
+    import torch
+    import relativisticraytracer_amd as rrt
+    from relativisticraytracer_amd import camera_paths as cp
+    from relativisticraytracer_amd.sky import synthetic_sky
+    out = tmp_path / "seq.rgba"
+    r = subprocess.run([sys.executable, "-m", "relativisticraytracer_amd.headless", "--width", "96", "--height", "54",
+                        "--frames", "3", "--path", "0", "--spin", "0.9", "--all-effects", "--out", str(out)],
+                       cwd=ROOT, capture_output=True, text=True, check=True)
+    meta = json.loads(r.stdout.strip().splitlines()[-1])
+    assert meta["frames"] == 3 and meta["path"] == "Gargantua Fly-By"
+    data = np.fromfile(out, np.uint8).reshape(3, 54, 96, 4)
+    tex = rrt.SkyTexture(synthetic_sky())
+    path = cp.CameraPath(0)
+    fx = rrt.CameraEffects(useChromaticAberration=True)
+    for k in (1, 2, 3):
+        st, pt = cp.recording_clock(k)
+        buf = torch.zeros(54 * 96 * 4, dtype=torch.uint8, device="cuda")
+        rrt.launch_raymarch(buf, 96, 54, st, path.camera_at(pt), tex, fx, rrt.RenderParams(spin=0.9))
+        torch.cuda.synchronize()
+        assert np.array_equal(buf.cpu().numpy().reshape(54, 96, 4), data[k - 1]), k

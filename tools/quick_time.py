@@ -9,12 +9,13 @@ w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 216
 spin = float(sys.argv[3]) if len(sys.argv) > 3 else 0.9
 vol = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+mode = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 tex = rrt.SkyTexture(synthetic_sky())
-cam = rrt.CameraState.default(); fx = rrt.CameraEffects(); prm = rrt.RenderParams(spin=spin, volumetrics=vol)
+cam = rrt.CameraState.default(); fx = rrt.CameraEffects(); prm = rrt.RenderParams(spin=spin, volumetrics=vol, arith_mode=mode)
 out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
 rrt.launch_raymarch(out, w, h, 1.0, cam, tex, fx, prm); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for r in range(reps):
     e0.record(); rrt.launch_raymarch(out, w, h, 1.0, cam, tex, fx, prm); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    print(f"{w}x{h} a={spin} vol={vol}: {ms:.2f} ms  {w*h/ms/1e3:.1f} Mrays/s", flush=True)
+    print(f"{w}x{h} a={spin} vol={vol} mode={mode}: {ms:.2f} ms  {w*h/ms/1e3:.1f} Mrays/s", flush=True)
