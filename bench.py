@@ -89,11 +89,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback in the product path)")
+    backend = os.environ.get("RRT_DIST_BACKEND", "nccl")        # "gloo": rehearsal on fewer GPUs than ranks
+    if backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     w, h, R = args.width, args.height, args.tile_rows
     sky_np = synthetic_sky(2048, 1024, seed=1)
@@ -132,7 +138,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev[args.warmup:]]

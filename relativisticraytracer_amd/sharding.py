@@ -69,6 +69,12 @@ class FrameSharder:
         self.frame = torch.zeros(height * width * 4, dtype=torch.uint8, device=device) if rank == 0 else None
         self.gathered = ([torch.zeros(self.n_bytes, dtype=torch.uint8, device=device) for _ in range(world)]
                          if (rank == 0 and world > 1) else None)
+        # rehearsal mode: a gloo group driving GPU buffers (several ranks sharing one card on a 1-GPU
+        # box) stages the gather through host memory; the production backend is nccl (= RCCL).
+        self.stage_cpu = False
+        if world > 1:
+            import torch.distributed as dist
+            self.stage_cpu = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
 
     def step(self):
         """Render this rank's tiles, gather to rank 0, assemble there.  Returns the frame on rank 0."""
@@ -77,7 +83,15 @@ class FrameSharder:
             self.assemble(self.frame, self.local, 0)
             return self.frame
         import torch.distributed as dist
-        dist.gather(self.local, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
+        if self.stage_cpu:
+            loc = self.local.cpu()
+            got = [self.torch.empty_like(loc) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(loc, got, dst=0, group=self.group)
+            if self.rank == 0:
+                for s in range(self.world):
+                    self.gathered[s].copy_(got[s])
+        else:
+            dist.gather(self.local, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
         if self.rank == 0:
             for s in range(self.world):
                 self.assemble(self.frame, self.gathered[s], s)
