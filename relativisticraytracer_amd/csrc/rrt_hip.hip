@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -88,24 +89,11 @@ __device__ __forceinline__ bool map_row(const RowMap& m, int height, int lr, int
     return true;
 }
 
-/*
- * Per-pixel pipeline, one ray per lane (reference raymarch_kernel,
- * src/raymarcher.cu:15-174).  A 256-thread workgroup covers a 16x16 pixel
- * block as four 8x8 wave tiles so that the 64 rays of a wavefront stay
- * spatially coherent (similar step counts, similar zone entry).
- */
-template <bool SPIN, bool VOL, bool DEBUG, bool FAST>
-__global__ __launch_bounds__(256) void raymarch_pixels(const FrameArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int lr = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    int y, out_row;
-    if (x >= a.width || !map_row(a.rows, a.height, lr, y, out_row)) return;
-
-    /* raymarcher.cu:20-34 */
-    float uvx = (float)x / (float)a.width;
-    float uvy = (float)y / (float)a.height;
-    if (a.use_lens) {                                   /* post_processing.h:19-24 */
+/* Primary ray of pixel (x, y): raymarcher.cu:20-34 (+ lens distortion, post_processing.h:19-24). */
+__device__ __forceinline__ void primary_ray(const FrameArgs& a, int x, int y, float& uvx, float& uvy, v3& p, v3& vel) {
+    uvx = (float)x / (float)a.width;
+    uvy = (float)y / (float)a.height;
+    if (a.use_lens) {
         float tx = uvx - 0.5f, ty = uvy - 0.5f;
         float r2 = tx * tx + ty * ty;
         float f = 1.0f + r2 * a.distortion_amount;
@@ -116,59 +104,17 @@ __global__ __launch_bounds__(256) void raymarch_pixels(const FrameArgs a) {
     float v_coord = uvy * 2.0f - 1.0f;
     float aspect = (float)a.width / (float)a.height;
     u_coord *= aspect;
-
     const v3 cfw = mk(a.cam.forward[0], a.cam.forward[1], a.cam.forward[2]);
     const v3 crt = mk(a.cam.right[0], a.cam.right[1], a.cam.right[2]);
     const v3 cup = mk(a.cam.up[0], a.cam.up[1], a.cam.up[2]);
-    v3 p = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
-    v3 vel = normalize(add(cfw, add(mul(crt, u_coord), mul(cup, v_coord))));
+    p = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
+    vel = normalize(add(cfw, add(mul(crt, u_coord), mul(cup, v_coord))));
+}
 
-    Radiance acc = {0.f, 0.f, 0.f, 1.0f};
-    bool hit = false;
-    int i = 0;
-
-    /* raymarcher.cu:41-121.  The step size takes three values (the `in_cloud_zone` arm of
-     * raymarcher.cu:62 is unreachable: the cloud zone lies inside the disk zone); h*0.5f and
-     * h/6.0f (integrators.h:31,57) are folded per value at compile time. */
-    constexpr float kHVac = kStepSize, kHNear = kStepSize * 0.1f, kHDisk = kStepSize * 0.3f;
-    for (; i < a.max_steps; ++i) {
-        const v3 rel_p = p;                             /* p - MASS_POS, MASS_POS = 0 */
-        float r2, r, y;
-        if (FAST) {
-            r2 = dot_fma(rel_p, rel_p);
-            y = __builtin_amdgcn_rsqf(r2);
-            r = r2 * y;
-            if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {
-                if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
-            }
-        } else {
-            r2 = dot(rel_p, rel_p);
-            sqrt_rsq(r2, r, y);
-            if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {
-                if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
-            }
-        }
-        if (r < kEventHorizon * 1.01f) { hit = true; acc.t = 0.0f; break; }
-
-        const bool near_bh = r < 18.0f;
-        const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
-        const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
-        const float h = near_bh ? kHNear : (in_disk ? kHDisk : kHVac);
-        const float hh = near_bh ? kHNear * 0.5f : (in_disk ? kHDisk * 0.5f : kHVac * 0.5f);
-        const float h6 = near_bh ? kHNear / 6.0f : (in_disk ? kHDisk / 6.0f : kHVac / 6.0f);
-
-        if (FAST) integrate_rk4_fast<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, y);
-        else integrate_rk4_r<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, r, y);
-
-        if (VOL && (in_disk || in_cloud)) {
-            float d_disk = in_disk ? accretion_density<true>(rel_p, a.time) : 0.0f;
-            float d_cloud = in_cloud ? dust_density(rel_p, a.time) : 0.0f;
-            accumulate_sample(acc, d_disk, d_cloud, rel_p, r, vel, h, a.spin);
-        }
-        if (r > 250.0f && dot(rel_p, vel) > 0.0f) { ++i; break; }
-    }
-
-    /* raymarcher.cu:124-150 */
+/* Everything after the march: sky, composition, post-FX, tone map, RGBA8 store -- raymarcher.cu:124-173. */
+template <bool DEBUG>
+__device__ __forceinline__ void shade_and_store(const FrameArgs& a, int x, int y, int out_row, float uvx, float uvy,
+                                                bool hit, v3 p, v3 vel, Radiance acc, int steps) {
     float bg_r = 0.f, bg_g = 0.f, bg_b = 0.f;
     if (!hit) {
         v3 d = normalize(vel);
@@ -213,12 +159,78 @@ __global__ __launch_bounds__(256) void raymarch_pixels(const FrameArgs a) {
         const size_t di = (size_t)y * a.width + x;
         if (a.dbg.d_ldr) { float* q = a.dbg.d_ldr + 4 * oi; q[0] = out_r; q[1] = out_g; q[2] = out_b; q[3] = 1.0f; }
         if (a.dbg.d_hdr) { float* q = a.dbg.d_hdr + 4 * oi; q[0] = hx; q[1] = hy; q[2] = hz; q[3] = 1.0f; }
-        if (a.dbg.d_steps) a.dbg.d_steps[di] = i;
+        if (a.dbg.d_steps) a.dbg.d_steps[di] = steps;
         if (a.dbg.d_hit) a.dbg.d_hit[di] = hit ? 1 : 0;
         if (a.dbg.d_pos) { float* q = a.dbg.d_pos + 3 * di; q[0] = p.x; q[1] = p.y; q[2] = p.z; }
         if (a.dbg.d_vel) { float* q = a.dbg.d_vel + 3 * di; q[0] = vel.x; q[1] = vel.y; q[2] = vel.z; }
         if (a.dbg.d_rad) { float* q = a.dbg.d_rad + 4 * di; q[0] = acc.r; q[1] = acc.g; q[2] = acc.b; q[3] = acc.t; }
     }
+}
+
+/* The step size takes three values (the `in_cloud_zone` arm of raymarcher.cu:62 is unreachable: the
+ * cloud zone lies inside the disk zone); h*0.5f and h/6.0f (integrators.h:31,57) are folded per value
+ * at compile time. */
+constexpr float kHVac = kStepSize, kHNear = kStepSize * 0.1f, kHDisk = kStepSize * 0.3f;
+
+/*
+ * Per-pixel pipeline, one ray per lane (reference raymarch_kernel, src/raymarcher.cu:15-174).
+ * A 256-thread workgroup covers a 16x16 pixel block as four 8x8 wave tiles so that the 64 rays of a
+ * wavefront stay spatially coherent (similar step counts, similar zone entry).
+ */
+template <bool SPIN, bool VOL, bool DEBUG, bool FAST>
+__global__ __launch_bounds__(256) void raymarch_pixels(const FrameArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int lr = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    int y, out_row;
+    if (x >= a.width || !map_row(a.rows, a.height, lr, y, out_row)) return;
+
+    float uvx, uvy;
+    v3 p, vel;
+    primary_ray(a, x, y, uvx, uvy, p, vel);
+
+    Radiance acc = {0.f, 0.f, 0.f, 1.0f};
+    bool hit = false;
+    int i = 0;
+
+    /* raymarcher.cu:41-121 */
+    for (; i < a.max_steps; ++i) {
+        const v3 rel_p = p;                             /* p - MASS_POS, MASS_POS = 0 */
+        float r2, r, y;
+        if (FAST) {
+            r2 = dot_fma(rel_p, rel_p);
+            y = __builtin_amdgcn_rsqf(r2);
+            r = r2 * y;
+            if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {
+                if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
+            }
+        } else {
+            r2 = dot(rel_p, rel_p);
+            sqrt_rsq(r2, r, y);
+            if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {
+                if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
+            }
+        }
+        if (r < kEventHorizon * 1.01f) { hit = true; acc.t = 0.0f; break; }
+
+        const bool near_bh = r < 18.0f;
+        const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
+        const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
+        const float h = near_bh ? kHNear : (in_disk ? kHDisk : kHVac);
+        const float hh = near_bh ? kHNear * 0.5f : (in_disk ? kHDisk * 0.5f : kHVac * 0.5f);
+        const float h6 = near_bh ? kHNear / 6.0f : (in_disk ? kHDisk / 6.0f : kHVac / 6.0f);
+
+        if (FAST) integrate_rk4_fast<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, y);
+        else integrate_rk4_r<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, r, y);
+
+        if (VOL && (in_disk || in_cloud)) {
+            float d_disk = in_disk ? accretion_density<true>(rel_p, a.time) : 0.0f;
+            float d_cloud = in_cloud ? dust_density(rel_p, a.time) : 0.0f;
+            accumulate_sample(acc, d_disk, d_cloud, rel_p, r, vel, h, a.spin);
+        }
+        if (r > 250.0f && dot(rel_p, vel) > 0.0f) { ++i; break; }
+    }
+    shade_and_store<DEBUG>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, i);
 }
 
 /* scatter one shard's tile buffer into the full bottom-up frame */
@@ -391,9 +403,9 @@ int fill_args(FrameArgs& a, bool& vol, bool& fast, void* out, int width, int hei
 
 int launch(const FrameArgs& a, bool vol, bool debug, bool fast, hipStream_t st) {
     dim3 block(256);
-    dim3 grid((a.width + 15) / 16, (a.rows.n_local_rows + 15) / 16);
-    if (grid.y == 0) return RRT_OK;
+    if (a.rows.n_local_rows == 0) return RRT_OK;
     const bool spin = a.spin != 0.0f;
+    dim3 grid((a.width + 15) / 16, (a.rows.n_local_rows + 15) / 16);
 #define RRT_LAUNCH(S, V, D) do { if (fast) hipLaunchKernelGGL((raymarch_pixels<S, V, D, true>), grid, block, 0, st, a); \
                                  else hipLaunchKernelGGL((raymarch_pixels<S, V, D, false>), grid, block, 0, st, a); } while (0)
     if (debug) {

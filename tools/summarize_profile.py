@@ -11,11 +11,13 @@ if ks:
         f.write(open(ks[0]).read())
     for r in rows:
         if "raymarch" in r["Name"]:
-            out["kernel"] = r["Name"]; out["calls"] = int(r["Calls"]); out["avg_ms"] = float(r["AverageNs"]) / 1e6
+            fast = r["Name"].split("(")[1].strip().endswith("true>") if False else ", true>(" in r["Name"]
+            key = "fast_mode_kernel" if fast else "kernel"
+            out[key] = r["Name"]; out[key + "_calls"] = int(r["Calls"]); out[key + "_avg_ms"] = float(r["AverageNs"]) / 1e6
 kt = glob.glob(f"{src}/trace/**/*kernel_trace.csv", recursive=True)
 if kt:
     for r in csv.DictReader(open(kt[0])):
-        if "raymarch" in r["Kernel_Name"]:
+        if "raymarch" in r["Kernel_Name"] and ", true>(" not in r["Kernel_Name"]:
             out["vgpr"] = int(r["VGPR_Count"]); out["sgpr"] = int(r["SGPR_Count"]); out["lds"] = int(r["LDS_Block_Size"])
             out["scratch"] = int(r["Scratch_Size"]); out["grid"] = [int(r["Grid_Size_X"]), int(r["Grid_Size_Y"])]
             break
@@ -26,7 +28,7 @@ for name in ("fetch", "write", "sq"):
     acc = {}
     n = {}
     for r in csv.DictReader(open(cs[0])):
-        if "raymarch" not in r["Kernel_Name"]:
+        if "raymarch" not in r["Kernel_Name"] or ", true>(" in r["Kernel_Name"]:
             continue
         acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         n[r["Counter_Name"]] = n.get(r["Counter_Name"], 0) + 1
