@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <unordered_map>
 
 #include "../../include/rrt.h"
 #include "rrt_device.h"
@@ -35,19 +36,30 @@ int hip_fail(hipError_t e, const char* what) {
         if (e_ != hipSuccess) return hip_fail(e_, #call);   \
     } while (0)
 
-/* ------------------------------------------------------------------ sky handles */
+/* ------------------------------------------------------------------ sky handles
+ * A handle is an id into a process-wide registry, never a raw pointer: a stale or made-up handle is
+ * reported as RRT_ERR_BAD_HANDLE instead of being dereferenced. */
 struct SkyObject {
-    uint32_t magic;
     uint8_t* d_texels;
     int w, h;
     bool owned;
 };
-constexpr uint32_t kSkyMagic = 0x52525453u; /* "RRTS" */
+std::mutex g_sky_mu;
+std::unordered_map<unsigned long long, SkyObject> g_sky;
+unsigned long long g_sky_next = 0x5254000000000001ull;
 
-SkyObject* sky_from_handle(rrt_sky_t h) {
-    SkyObject* s = reinterpret_cast<SkyObject*>(static_cast<uintptr_t>(h));
-    if (!s || s->magic != kSkyMagic) return nullptr;
-    return s;
+bool sky_lookup(rrt_sky_t h, SkyObject& out) {
+    std::lock_guard<std::mutex> lk(g_sky_mu);
+    auto it = g_sky.find(h);
+    if (it == g_sky.end()) return false;
+    out = it->second;
+    return true;
+}
+rrt_sky_t sky_register(const SkyObject& s) {
+    std::lock_guard<std::mutex> lk(g_sky_mu);
+    rrt_sky_t h = g_sky_next++;
+    g_sky.emplace(h, s);
+    return h;
 }
 
 /* ------------------------------------------------------------------ kernel arguments */
@@ -382,8 +394,9 @@ int fill_args(FrameArgs& a, bool& vol, bool& fast, void* out, int width, int hei
               rrt_sky_t sky, const rrt_effects* fx, const rrt_params* prm_in) {
     rrt_params prm;
     if (prm_in) prm = *prm_in; else rrt_params_default(&prm);
-    SkyObject* s = sky_from_handle(sky);
-    if (!s) return RRT_ERR_BAD_HANDLE;
+    SkyObject so;
+    if (!sky_lookup(sky, so)) return RRT_ERR_BAD_HANDLE;
+    const SkyObject* s = &so;
     a.out = static_cast<uchar4*>(out);
     a.width = width; a.height = height; a.time = time; a.cam = *cam;
     a.sky.texels = s->d_texels; a.sky.w = s->w; a.sky.h = s->h; a.sky.frac_bits = prm.sky_frac_bits;
@@ -488,39 +501,37 @@ int rrt_effects_default(rrt_effects* e) {    /* camera_settings.h:5-16 */
 
 int rrt_sky_create(const uint8_t* rgba8_host, int width, int height, rrt_sky_t* out) {
     if (!rgba8_host || !out || width <= 0 || height <= 0) return RRT_ERR_INVALID_ARGUMENT;
-    SkyObject* s = new (std::nothrow) SkyObject;
-    if (!s) return RRT_ERR_OUT_OF_MEMORY;
+    SkyObject s{nullptr, width, height, true};
     size_t bytes = (size_t)width * height * 4;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_texels), bytes);
-    if (e != hipSuccess) { delete s; return hip_fail(e, "hipMalloc(sky)"); }
-    e = hipMemcpy(s->d_texels, rgba8_host, bytes, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(s->d_texels); delete s; return hip_fail(e, "hipMemcpy(sky)"); }
-    s->magic = kSkyMagic; s->w = width; s->h = height; s->owned = true;
-    *out = static_cast<rrt_sky_t>(reinterpret_cast<uintptr_t>(s));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s.d_texels), bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(sky)");
+    e = hipMemcpy(s.d_texels, rgba8_host, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(s.d_texels); return hip_fail(e, "hipMemcpy(sky)"); }
+    *out = sky_register(s);
     return RRT_OK;
 }
 
 int rrt_sky_create_from_device(const void* d_rgba8, int width, int height, rrt_sky_t* out) {
     if (!d_rgba8 || !out || width <= 0 || height <= 0) return RRT_ERR_INVALID_ARGUMENT;
-    SkyObject* s = new (std::nothrow) SkyObject;
-    if (!s) return RRT_ERR_OUT_OF_MEMORY;
-    s->magic = kSkyMagic; s->d_texels = const_cast<uint8_t*>(static_cast<const uint8_t*>(d_rgba8));
-    s->w = width; s->h = height; s->owned = false;
-    *out = static_cast<rrt_sky_t>(reinterpret_cast<uintptr_t>(s));
+    SkyObject s{const_cast<uint8_t*>(static_cast<const uint8_t*>(d_rgba8)), width, height, false};
+    *out = sky_register(s);
     return RRT_OK;
 }
 
 int rrt_sky_destroy(rrt_sky_t sky) {
-    SkyObject* s = sky_from_handle(sky);
-    if (!s) return RRT_ERR_BAD_HANDLE;
-    int rc = RRT_OK;
-    if (s->owned) {
-        hipError_t e = hipFree(s->d_texels);
-        if (e != hipSuccess) rc = hip_fail(e, "hipFree(sky)");
+    SkyObject s;
+    {
+        std::lock_guard<std::mutex> lk(g_sky_mu);
+        auto it = g_sky.find(sky);
+        if (it == g_sky.end()) return RRT_ERR_BAD_HANDLE;
+        s = it->second;
+        g_sky.erase(it);
     }
-    s->magic = 0;
-    delete s;
-    return rc;
+    if (s.owned) {
+        hipError_t e = hipFree(s.d_texels);
+        if (e != hipSuccess) return hip_fail(e, "hipFree(sky)");
+    }
+    return RRT_OK;
 }
 
 int rrt_launch_raymarch_rows(void* d_out_rows, int width, int height, int y0, int y1, float time,
@@ -633,9 +644,9 @@ int rrt_unit_math(int fn, int n, const float* a, const float* b, float* out, voi
 int rrt_unit_sky_sample(int n, const float* dir, float off, rrt_sky_t sky, int frac_bits, float* out, void* st) {
     if (n > 0 && (!dir || !out)) return RRT_ERR_INVALID_ARGUMENT;
     if (frac_bits < 0 || frac_bits > 16) return RRT_ERR_INVALID_ARGUMENT;
-    SkyObject* so = sky_from_handle(sky);
-    if (!so) return RRT_ERR_BAD_HANDLE;
-    SkyTex t{so->d_texels, so->w, so->h, frac_bits};
+    SkyObject so;
+    if (!sky_lookup(sky, so)) return RRT_ERR_BAD_HANDLE;
+    SkyTex t{so.d_texels, so.w, so.h, frac_bits};
     return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_sky, g, b, 0, s, n, dir, off, t, out); });
 }
 

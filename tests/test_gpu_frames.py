@@ -196,6 +196,47 @@ def test_fast_mode_statistics(ctx):
     assert rel_ok.mean() >= 0.80
 
 
+def test_streams_graph_capture_and_borrowed_sky(ctx, sky):
+    """The launch allocates nothing and keeps no state: it runs on a side stream, can be captured into a
+    HIP graph and replayed, and accepts a sky that lives in caller-owned device memory."""
+    import ctypes as C
+    import torch
+    g, rrt, tex = ctx
+    from relativisticraytracer_amd import _lib
+    w, h = 128, 72
+    cam = rrt.CameraState.default(); fx = rrt.CameraEffects(); prm = rrt.RenderParams(spin=0.9)
+    ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+    rrt.launch_raymarch(ref, w, h, 1.0, cam, tex, fx, prm)
+    torch.cuda.synchronize()
+    # side stream
+    side = torch.cuda.Stream()
+    a = torch.zeros_like(ref)
+    rrt.launch_raymarch(a, w, h, 1.0, cam, tex, fx, prm, stream=side)
+    side.synchronize()
+    assert torch.equal(a, ref)
+    # graph capture + two replays
+    b = torch.zeros_like(ref)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        rrt.launch_raymarch(b, w, h, 1.0, cam, tex, fx, prm)
+    for _ in range(2):
+        b.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(b, ref)
+    # borrowed device sky
+    dsky = torch.from_numpy(sky).cuda()
+    hnd = C.c_ulonglong(0)
+    _lib.check(_lib.load().rrt_sky_create_from_device(C.c_void_p(dsky.data_ptr()), sky.shape[1], sky.shape[0],
+                                                      C.byref(hnd)), "sky_from_device")
+    c = torch.zeros_like(ref)
+    rrt.launch_raymarch(c, w, h, 1.0, cam, hnd.value, fx, prm)
+    torch.cuda.synchronize()
+    assert torch.equal(c, ref)
+    assert _lib.load().rrt_sky_destroy(hnd.value) == 0
+    assert _lib.load().rrt_sky_destroy(hnd.value) in (4,)        # double destroy is reported, not fatal
+
+
 def test_launch_argument_errors(ctx):
     import ctypes as C
     import torch
