@@ -44,6 +44,14 @@ def cpu_baseline(width, height, spin, stride, sky):
     from oracle import pyoracle as po
     import relativisticraytracer_amd as rrt
     po.build()
+    native = po.use_native_build()      # -O3 -march=native build of the same source, made on this host
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
     a = rrt.CameraState.default().as_array()
     cam = po.camera(a[0], a[1], a[2], a[3])
     prm = po.default_params(spin=spin)
@@ -57,6 +65,9 @@ def cpu_baseline(width, height, spin, stride, sky):
     n = int(sel.sum())
     means = {k: float(r[k][sel].mean()) for k in ("steps", "n_noise", "n_dens", "n_samples")}
     return {"value": n / dt / 1e6, "unit": "Mrays/s", "cores": nthreads, "kind": "port",
+            "cpu_model": cpu_model,
+            "build": "gcc -O3 -march=native -ffp-contract=off -fopenmp" if native else
+                     "gcc -O2 -mfma -ffp-contract=off -fopenmp",
             "sample": f"every {stride}th pixel in x and y of the same {width}x{height} frame "
                       f"({n} rays, {dt:.1f} s wall, oracle/rrt_oracle.c, libm math, OpenMP dynamic rows)"}, means
 
@@ -122,6 +133,19 @@ def main():
         rrt.assemble_tiles(frame, buf, w, h, R, shard, world)
 
     fs = sharding.FrameSharder(w, h, R, rank, world, dev, render, assemble)
+
+    # Untimed one-off setup, so that even --warmup 0 times steady-state steps: load the code object with a
+    # tiny launch, and bring up the RCCL communicator / its peer-to-peer channels with one small collective
+    # of each kind the step uses.
+    tiny = torch.zeros(16 * 16 * 4, dtype=torch.uint8, device=dev)
+    rrt.launch_raymarch(tiny, 16, 16, 1.0, cam, tex, fx, rrt.RenderParams(spin=args.spin, max_steps=4))
+    if world > 1:
+        probe = torch.zeros(4096, dtype=torch.uint8, device=dev)
+        if fs.stage_cpu:
+            probe = probe.cpu()
+        dist.gather(probe, [torch.zeros_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
+        dist.barrier()
+    torch.cuda.synchronize()
 
     def barrier():
         torch.cuda.synchronize()

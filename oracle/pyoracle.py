@@ -67,6 +67,22 @@ def lib():
     return _lib
 
 
+def use_native_build():
+    """Switch this process to a -O3 -march=native build of the same oracle source, compiled on this
+    machine (bench.py's cpu_baseline leg).  Returns True if it could be built and loaded."""
+    global _lib
+    try:
+        subprocess.run(["make", "-C", HERE, "native"], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+        nl = C.CDLL(os.path.join(HERE, "librrt_oracle_native.so"))
+        nl.rrto_render.restype = _i
+        nl.rrto_max_threads.restype = _i
+        _lib = nl
+        return True
+    except Exception:
+        return False
+
+
 def _fa(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
