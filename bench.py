@@ -132,7 +132,10 @@ def main():
     def assemble(frame, buf, shard):
         rrt.assemble_tiles(frame, buf, w, h, R, shard, world)
 
-    fs = sharding.FrameSharder(w, h, R, rank, world, dev, render, assemble)
+    def assemble_all(frame, bufs, stride):
+        rrt.assemble_all_tiles(frame, bufs, stride, w, h, R, world)
+
+    fs = sharding.FrameSharder(w, h, R, rank, world, dev, render, assemble, assemble_all=assemble_all)
 
     # Untimed one-off setup, so that even --warmup 0 times steady-state steps: load the code object with a
     # tiny launch, and bring up the RCCL communicator / its peer-to-peer channels with one small collective

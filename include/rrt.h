@@ -151,6 +151,11 @@ int rrt_tile_shard_rows(int height, int tile_rows, int shard, int n_shards, int*
 int rrt_assemble_tiles(void* d_frame_rgba8, const void* d_tiles, int width, int height,
                        int tile_rows, int shard, int n_shards, void* stream);
 
+/* Same for ALL shards in one launch: shard s's buffer starts at d_tiles_all + s*shard_stride_bytes
+ * (the layout a gather into one allocation produces). */
+int rrt_assemble_all_tiles(void* d_frame_rgba8, const void* d_tiles_all, size_t shard_stride_bytes,
+                           int width, int height, int tile_rows, int n_shards, void* stream);
+
 /* Full-frame launch that also fills per-ray debug outputs (parity tests). */
 int rrt_launch_raymarch_ex(void* d_out_rgba8, int width, int height, float time,
                            const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx,

@@ -22,7 +22,8 @@ from . import _lib
 from ._lib import RRTError, rrt_camera, rrt_debug_outputs, rrt_effects, rrt_params  # noqa: F401
 
 __all__ = ["CameraState", "CameraEffects", "RenderParams", "SkyTexture", "launch_raymarch",
-           "launch_raymarch_rows", "launch_raymarch_tiles", "assemble_tiles", "tile_shard_rows",
+           "launch_raymarch_rows", "launch_raymarch_tiles", "assemble_tiles", "assemble_all_tiles",
+           "tile_shard_rows",
            "launch_raymarch_debug", "RRTError", "device_count", "abi_version"]
 
 
@@ -194,6 +195,11 @@ def tile_shard_rows(h, tile_rows, shard, n_shards):
 def assemble_tiles(d_frame, d_tiles, w, h, tile_rows, shard, n_shards, stream=None):
     _lib.check(_lib.load().rrt_assemble_tiles(_ptr(d_frame), _ptr(d_tiles), w, h, tile_rows, shard, n_shards,
                                               _stream(stream)), "rrt_assemble_tiles")
+
+
+def assemble_all_tiles(d_frame, d_tiles_all, shard_stride_bytes, w, h, tile_rows, n_shards, stream=None):
+    _lib.check(_lib.load().rrt_assemble_all_tiles(_ptr(d_frame), _ptr(d_tiles_all), shard_stride_bytes, w, h,
+                                                  tile_rows, n_shards, _stream(stream)), "rrt_assemble_all_tiles")
 
 
 def launch_raymarch_debug(d_out, w, h, time, cam, skyboxTex, effects, params=None, stream=None, **outs):

@@ -65,6 +65,7 @@ SYMBOLS = [
     ("rrt_launch_raymarch_tiles", _i, [_vp, _i, _i, _i, _i, _i, _f, _cam, _ull, _fx, _prm, _vp]),
     ("rrt_tile_shard_rows", _i, [_i, _i, _i, _i, C.POINTER(_i)]),
     ("rrt_assemble_tiles", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    ("rrt_assemble_all_tiles", _i, [_vp, _vp, C.c_size_t, _i, _i, _i, _i, _vp]),
     ("rrt_launch_raymarch_ex", _i, [_vp, _i, _i, _f, _cam, _ull, _fx, _prm,
                                     C.POINTER(rrt_debug_outputs), _vp]),
     ("rrt_unit_geodesic_acc", _i, [_i, _vp, _vp, _f, _vp, _vp]),

@@ -255,6 +255,19 @@ __global__ __launch_bounds__(256) void assemble_tiles_kernel(uchar4* frame, cons
     frame[(size_t)(height - 1 - y) * width + x] = tiles[(size_t)out_row * width + x];
 }
 
+/* all shards in one launch: `tiles` holds n_shards buffers, `shard_stride` pixels apart */
+__global__ __launch_bounds__(256) void assemble_all_kernel(uchar4* frame, const uchar4* tiles, size_t shard_stride,
+                                                          int width, int height, int tile_rows, int n_shards) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;                               /* image row */
+    if (x >= width || y >= height) return;
+    const int t = y / tile_rows, rr = y - t * tile_rows;
+    const int shard = t % n_shards, k = t / n_shards;
+    const int rows_k = min(tile_rows, height - t * tile_rows);
+    const size_t src_row = (size_t)k * tile_rows + (rows_k - 1 - rr);
+    frame[(size_t)(height - 1 - y) * width + x] = tiles[shard * shard_stride + src_row * width + x];
+}
+
 /* ------------------------------------------------------------------ unit kernels */
 __device__ __forceinline__ v3 ld3(const float* a, int i) { return mk(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
 __device__ __forceinline__ void st3(float* a, int i, v3 v) { a[3 * i] = v.x; a[3 * i + 1] = v.y; a[3 * i + 2] = v.z; }
@@ -598,6 +611,20 @@ int rrt_assemble_tiles(void* d_frame, const void* d_tiles, int width, int height
     dim3 grid((width + 255) / 256, m.n_local_rows);
     hipLaunchKernelGGL(assemble_tiles_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<uchar4*>(d_frame), static_cast<const uchar4*>(d_tiles), width, height, m);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+
+int rrt_assemble_all_tiles(void* d_frame, const void* d_tiles_all, size_t shard_stride_bytes, int width, int height,
+                           int tile_rows, int n_shards, void* stream) {
+    if (!d_frame || !d_tiles_all || width <= 0 || height <= 0 || tile_rows <= 0 || n_shards <= 0 ||
+        (shard_stride_bytes & 3) != 0)
+        return RRT_ERR_INVALID_ARGUMENT;
+    if (shard_stride_bytes / 4 < (size_t)shard_rows(height, tile_rows, 0, n_shards) * width) return RRT_ERR_INVALID_ARGUMENT;
+    dim3 grid((width + 255) / 256, height);
+    hipLaunchKernelGGL(assemble_all_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<uchar4*>(d_frame), static_cast<const uchar4*>(d_tiles_all), shard_stride_bytes / 4,
+                       width, height, tile_rows, n_shards);
     RRT_HIP(hipGetLastError());
     return RRT_OK;
 }

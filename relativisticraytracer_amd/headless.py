@@ -69,7 +69,10 @@ def main(argv=None):
     def assemble(frame, buf, shard):
         rrt.assemble_tiles(frame, buf, w, h, args.tile_rows, shard, world)
 
-    fs = sharding.FrameSharder(w, h, args.tile_rows, rank, world, dev, render, assemble)
+    def assemble_all(frame, bufs, stride):
+        rrt.assemble_all_tiles(frame, bufs, stride, w, h, args.tile_rows, world)
+
+    fs = sharding.FrameSharder(w, h, args.tile_rows, rank, world, dev, render, assemble, assemble_all=assemble_all)
     sink = sinks.open_sink(args.out, w, h, args.fps) if rank == 0 else None
     host = torch.empty(h * w * 4, dtype=torch.uint8, pin_memory=True) if sink else None
 

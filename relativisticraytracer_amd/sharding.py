@@ -55,20 +55,24 @@ class FrameSharder:
 
     render(buf)            fills this rank's tile buffer (a (pad_rows*width*4,) uint8 tensor)
     assemble(frame, buf, shard)   scatters one shard's buffer into the full frame (rank 0 only)
+    assemble_all(frame, all_bufs, stride_bytes)   optional: all shards in one launch
     """
 
-    def __init__(self, width, height, tile_rows, rank, world, device, render, assemble, group=None):
+    def __init__(self, width, height, tile_rows, rank, world, device, render, assemble, group=None,
+                 assemble_all=None):
         import torch
         self.torch = torch
         self.width, self.height, self.tile_rows = width, height, tile_rows
         self.rank, self.world, self.group = rank, world, group
         self.pad_rows = max_shard_rows(height, tile_rows, world)
         self.n_bytes = self.pad_rows * width * 4
-        self.render, self.assemble = render, assemble
+        self.render, self.assemble, self.assemble_all = render, assemble, assemble_all
         self.local = torch.zeros(self.n_bytes, dtype=torch.uint8, device=device)
         self.frame = torch.zeros(height * width * 4, dtype=torch.uint8, device=device) if rank == 0 else None
-        self.gathered = ([torch.zeros(self.n_bytes, dtype=torch.uint8, device=device) for _ in range(world)]
-                         if (rank == 0 and world > 1) else None)
+        # one allocation for all shards, so that a single assemble launch can read them (assemble_all)
+        self.gathered_all = (torch.zeros(world * self.n_bytes, dtype=torch.uint8, device=device)
+                             if (rank == 0 and world > 1) else None)
+        self.gathered = (list(self.gathered_all.split(self.n_bytes)) if self.gathered_all is not None else None)
         # rehearsal mode: a gloo group driving GPU buffers (several ranks sharing one card on a 1-GPU
         # box) stages the gather through host memory; the production backend is nccl (= RCCL).
         self.stage_cpu = False
@@ -93,6 +97,9 @@ class FrameSharder:
         else:
             dist.gather(self.local, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
         if self.rank == 0:
-            for s in range(self.world):
-                self.assemble(self.frame, self.gathered[s], s)
+            if self.assemble_all is not None:
+                self.assemble_all(self.frame, self.gathered_all, self.n_bytes)
+            else:
+                for s in range(self.world):
+                    self.assemble(self.frame, self.gathered[s], s)
         return self.frame

@@ -141,6 +141,15 @@ def test_row_and_tile_shards_reassemble_to_the_full_frame(ctx):
             rrt.assemble_tiles(tiles, buf, w, h, R, s, n_shards)
         torch.cuda.synchronize()
         assert torch.equal(tiles, full), (n_shards, R)
+        # all shards gathered into one allocation, assembled by one launch (what rank 0 does after the gather)
+        pad = max(rrt.tile_shard_rows(h, R, s, n_shards) for s in range(n_shards)) * w * 4
+        allbuf = torch.zeros(n_shards * pad, dtype=torch.uint8, device="cuda")
+        for s in range(n_shards):
+            rrt.launch_raymarch_tiles(allbuf[s * pad:], w, h, R, s, n_shards, 1.0, cam, tex, fx, prm)
+        tiles.zero_()
+        rrt.assemble_all_tiles(tiles, allbuf, pad, w, h, R, n_shards)
+        torch.cuda.synchronize()
+        assert torch.equal(tiles, full), ("all", n_shards, R)
     torch.cuda.synchronize()
     assert torch.equal(rows, full)
     assert sum(rrt.tile_shard_rows(h, 8, s, 3) for s in range(3)) == h
