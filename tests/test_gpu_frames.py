@@ -117,6 +117,30 @@ def test_effect_toggles_and_edge_sizes(ctx, po, sky):
     assert np.array_equal(r["rgba8"], o["rgba8"])
 
 
+@pytest.mark.parametrize("pos,yaw,pitch,spin", [
+    ((0.0, 0.5, 0.0), 0.0, 0.0, 0.9),          # camera inside r < 1: the geodesics.h:33 guard, instant horizon
+    ((0.0, 1.5, -1.0), 10.0, -30.0, 0.9),      # inside the horizon radius 2.02: every ray ends at step 0
+    ((0.0, 2.5, -2.0), 0.0, -40.0, 0.99),      # just outside the horizon, looking in and out
+    ((3000.0, 40.0, 0.0), -90.0, 0.0, 0.9),    # far away: rays looking outward escape after one step
+    ((14.0, 0.05, 3.0), 200.0, 2.0, 0.9),      # inside the disk, in both media zones from step 0
+    ((0.0, 60.0, 0.0), 0.0, -89.9, 0.0),       # straight down the spin axis, a = 0 (exact symmetries, +-0)
+])
+def test_unusual_cameras_match_oracle(ctx, po, sky, pos, yaw, pitch, spin):
+    g, rrt, tex = ctx
+    w, h = 48, 28
+    cam = rrt.CameraState.from_angles(pos, yaw, pitch)
+    fx = rrt.CameraEffects(useChromaticAberration=True)
+    r = g.render_gpu(w, h, spin, 1, cam, 2.5, tex, fx=fx)
+    a = cam.as_array()
+    o = po.render(po.camera(a[0], a[1], a[2], a[3]), po.default_effects(use_ca=1),
+                  po.default_params(spin=spin, math_mode=po.MATH_PORTABLE), 2.5, w, h, sky,
+                  want=("rgba8", "ldr", "diag"))
+    assert np.array_equal(r["steps"], o["steps"])
+    assert np.array_equal(r["hit"], o["hit"])
+    assert np.array_equal(r["rgba8"], o["rgba8"])
+    assert same_bits(r["ldr"], o["ldr"])
+
+
 def test_row_and_tile_shards_reassemble_to_the_full_frame(ctx):
     """Sharded renders must be byte-identical to the single launch."""
     import torch
