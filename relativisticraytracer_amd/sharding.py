@@ -76,9 +76,23 @@ class FrameSharder:
         # rehearsal mode: a gloo group driving GPU buffers (several ranks sharing one card on a 1-GPU
         # box) stages the gather through host memory; the production backend is nccl (= RCCL).
         self.stage_cpu = False
+        self.use_allgather = False
         if world > 1:
             import torch.distributed as dist
             self.stage_cpu = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
+            # Bring the communicator up with the collective the step uses (untimed, once).  `gather` is what
+            # the path needs (only rank 0 assembles); should a backend build lack it, every rank sees the
+            # same exception here and the step falls back to an all-gather of the same buffers.
+            probe = torch.zeros(256, dtype=torch.uint8, device="cpu" if self.stage_cpu else device)
+            try:
+                dist.gather(probe, [torch.zeros_like(probe) for _ in range(world)] if rank == 0 else None,
+                            dst=0, group=group)
+            except (RuntimeError, NotImplementedError):
+                self.use_allgather = True
+                if self.gathered_all is None:
+                    self.gathered_all = torch.zeros(world * self.n_bytes, dtype=torch.uint8, device=device)
+                dist.all_gather_into_tensor(torch.zeros(world * 256, dtype=torch.uint8, device=probe.device), probe,
+                                            group=group)
 
     def step(self):
         """Render this rank's tiles, gather to rank 0, assemble there.  Returns the frame on rank 0."""
@@ -87,7 +101,9 @@ class FrameSharder:
             self.assemble(self.frame, self.local, 0)
             return self.frame
         import torch.distributed as dist
-        if self.stage_cpu:
+        if self.use_allgather:
+            dist.all_gather_into_tensor(self.gathered_all, self.local, group=self.group)
+        elif self.stage_cpu:
             loc = self.local.cpu()
             got = [self.torch.empty_like(loc) for _ in range(self.world)] if self.rank == 0 else None
             dist.gather(loc, got, dst=0, group=self.group)

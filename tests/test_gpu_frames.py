@@ -291,6 +291,31 @@ def test_launch_argument_errors(ctx):
         rrt.launch_raymarch(out, -1, 4, 0.0, cam, tex, fx)
 
 
+@pytest.mark.parametrize("w,h,spin,t,stride", [
+    (1920, 1080, 0.9, 1.0, 53),       # BASELINE configs[1]/[2] size
+    (3840, 2160, 0.9, 1.0, 97),       # the bench frame (BASELINE metric config)
+    (3840, 2160, 0.99, 1.0, 101),     # configs[3]
+    (7680, 4320, 0.9, 3.0, 211),      # configs[4] size
+])
+def test_full_size_frames_sampled_against_oracle(ctx, po, sky, w, h, spin, t, stride):
+    """Full-size frames: the oracle renders every `stride`-th pixel in x and y of the SAME frame
+    (hundreds to thousands of rays) and those pixels must carry identical bytes in the GPU frame."""
+    import torch
+    g, rrt, tex = ctx
+    cam = rrt.CameraState.default(); fx = rrt.CameraEffects(); prm = rrt.RenderParams(spin=spin)
+    out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+    rrt.launch_raymarch(out, w, h, t, cam, tex, fx, prm)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(h, w, 4)
+    a = cam.as_array()
+    o = po.render(po.camera(a[0], a[1], a[2], a[3]), po.default_effects(),
+                  po.default_params(spin=spin, math_mode=po.MATH_PORTABLE), t, w, h, sky, stride=(stride, stride))["rgba8"]
+    ys = np.arange(0, h, stride); xs = np.arange(0, w, stride)
+    rows = (h - 1 - ys)                                   # bottom-up storage
+    assert np.array_equal(got[np.ix_(rows, xs)], o[np.ix_(rows, xs)])
+    assert got[np.ix_(rows, xs)][..., :3].any()
+
+
 def test_full_size_properties_4k(ctx):
     """BASELINE config at full size: properties that need no oracle.
     Two launches give identical bytes (no races); every alpha is 255; the image is left-right
