@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=16)
     ap.add_argument("--cpu-stride", type=int, default=8, help="CPU baseline sample stride (0 = skip)")
     ap.add_argument("--no-fast", action="store_true", help="skip the informational RRT_ARITH_FAST leg")
+    ap.add_argument("--workspace-gib", type=int, default=6, help="per-rank pool for the three-pass path (N > 1)")
     args = ap.parse_args()
 
     import numpy as np
@@ -116,7 +117,11 @@ def main():
     sky_np = synthetic_sky(2048, 1024, seed=1)
     tex = rrt.SkyTexture(sky_np)
     cam, fx = rrt.CameraState.default(), rrt.CameraEffects()
-    prm = rrt.RenderParams(spin=args.spin, volumetrics=1)
+    # With several ranks every launch is a fraction of the frame; the library then prefers its three-pass
+    # path for small launches (rrt_params.path_policy = auto), which needs a caller-owned pool.
+    ws = rrt.Workspace(args.workspace_gib << 30) if (world > 1 and args.workspace_gib > 0) else None
+    prm = rrt.RenderParams(spin=args.spin, volumetrics=1, workspace=ws.id if ws else 0,
+                           path_policy=int(os.environ.get("RRT_PATH_POLICY", "0")))
 
     kernel_ms = []
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -227,7 +232,8 @@ def main():
             "config": {"workload": f"{w}x{h} Kerr a={args.spin:g} full volumetric disk+dust, default camera "
                                    f"(0,10,-60) yaw 0 pitch -10, t=1.0, default effects, synthetic 2048x1024 sky seed 1",
                        "rays_per_frame": rays, "max_steps": 2000, "arith_mode": "strict (bit-exact vs oracle)",
-                       "parallelism": f"rowtiles{R}x{world}" if world > 1 else "single"},
+                       "parallelism": f"rowtiles{R}x{world}" if world > 1 else "single",
+                       "path": ("auto: three-pass below 1.5 M rays per launch, %d GiB pool" % args.workspace_gib) if ws else "single kernel"},
             "roofline": {"bound": "valu", "achieved": round(tops, 3), "peak": round(VALU_PEAK_TOPS, 2),
                          "unit": "TFLOP/s", "frac": round(tops / VALU_PEAK_TOPS, 4), "traffic": traffic,
                          "kernel": "raymarch_pixels", "kernel_ms": round(k_ms, 3),
@@ -244,6 +250,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if ws:
+        ws.destroy()
     tex.destroy()
 
 

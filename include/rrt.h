@@ -84,8 +84,21 @@ typedef struct rrt_params {
                                 RRT_ARITH_FAST: fused multiply-adds and 1-ulp reciprocal
                                 square roots in the geodesic integrator; NOT bit-comparable
                                 with the oracle                      */
-    int32_t reserved[3];     /* must be 0 */
+    int32_t workspace;       /* 0 (default): single kernel, media sampled in line by the marching
+                                lane.  An rrt_workspace id: three-pass path -- the march only
+                                records in-medium sample points, which the whole chip then evaluates
+                                and a last pass composites in march order.  Same bytes out; removes
+                                the per-wavefront long pole of disk-grazing rays, which is what
+                                strong scaling over GPUs needs.           */
+    int32_t path_policy;     /* with a workspace: RRT_PATH_AUTO (default) takes the three-pass path for
+                                launches of <= 1.5 M rays (where it is faster) and the single kernel
+                                otherwise; RRT_PATH_SINGLE / RRT_PATH_THREE_PASS force one             */
+    int32_t reserved[1];     /* must be 0 */
 } rrt_params;
+
+#define RRT_PATH_AUTO 0
+#define RRT_PATH_SINGLE 1
+#define RRT_PATH_THREE_PASS 2
 
 #define RRT_ARITH_STRICT 0
 #define RRT_ARITH_FAST 1
@@ -120,6 +133,17 @@ int rrt_effects_default(rrt_effects* fx);      /* camera_settings.h:5-16 default
 int rrt_sky_create(const uint8_t* rgba8_host, int width, int height, rrt_sky_t* out);
 int rrt_sky_create_from_device(const void* d_rgba8, int width, int height, rrt_sky_t* out); /* borrows */
 int rrt_sky_destroy(rrt_sky_t sky);
+
+/* ---- workspace of the three-pass path (rrt_params.workspace): a caller-owned HBM pool, so that a
+ *      launch still allocates nothing.  One workspace serves one stream at a time.  ~1.5 KB per
+ *      wave-step that touches the media (handed out in blocks of 8); the 4K bench frame uses ~4 GB.  If the pool runs out, the
+ *      affected wavefronts are rendered by the in-line code instead (same result, slower). ---- */
+int rrt_workspace_create(size_t bytes, int* out_id);
+int rrt_workspace_destroy(int id);
+/* after a launch has completed: rows used and wavefronts that fell back (synchronous read) */
+int rrt_workspace_stats(int id, unsigned* rows_used, unsigned* overflow_waves);
+/* inspection: copy `bytes` of the pool starting at `offset` to host memory (synchronous) */
+int rrt_workspace_read(int id, size_t offset, size_t bytes, void* host_dst);
 
 /* ---- the hot path.  Replaces launch_raymarch, reference include/raymarcher.h:19 /
  *      src/raymarcher.cu:176-180.  Writes width*height RGBA8 pixels, alpha 255,

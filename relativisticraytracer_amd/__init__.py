@@ -21,7 +21,7 @@ import numpy as np
 from . import _lib
 from ._lib import RRTError, rrt_camera, rrt_debug_outputs, rrt_effects, rrt_params  # noqa: F401
 
-__all__ = ["CameraState", "CameraEffects", "RenderParams", "SkyTexture", "launch_raymarch",
+__all__ = ["CameraState", "CameraEffects", "RenderParams", "SkyTexture", "Workspace", "launch_raymarch",
            "launch_raymarch_rows", "launch_raymarch_tiles", "assemble_tiles", "assemble_all_tiles",
            "tile_shard_rows",
            "launch_raymarch_debug", "RRTError", "device_count", "abi_version"]
@@ -138,6 +138,31 @@ class SkyTexture:
         if getattr(self, "handle", 0):
             _lib.load().rrt_sky_destroy(self.handle)
             self.handle = 0
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Workspace:
+    """Caller-owned HBM pool for the three-pass path (RenderParams.workspace = ws.id)."""
+
+    def __init__(self, nbytes):
+        i = C.c_int(0)
+        _lib.check(_lib.load().rrt_workspace_create(int(nbytes), C.byref(i)), "rrt_workspace_create")
+        self.id, self.nbytes = i.value, int(nbytes)
+
+    def stats(self):
+        rows, ovf = C.c_uint(0), C.c_uint(0)
+        _lib.check(_lib.load().rrt_workspace_stats(self.id, C.byref(rows), C.byref(ovf)), "rrt_workspace_stats")
+        return {"rows_used": rows.value, "overflow_waves": ovf.value}
+
+    def destroy(self):
+        if getattr(self, "id", 0):
+            _lib.load().rrt_workspace_destroy(self.id)
+            self.id = 0
 
     def __del__(self):
         try:

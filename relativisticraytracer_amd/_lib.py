@@ -38,7 +38,8 @@ class rrt_effects(C.Structure):
 
 class rrt_params(C.Structure):
     _fields_ = [("spin", C.c_float), ("max_steps", C.c_int32), ("volumetrics", C.c_int32),
-                ("sky_frac_bits", C.c_int32), ("arith_mode", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("sky_frac_bits", C.c_int32), ("arith_mode", C.c_int32), ("workspace", C.c_int32),
+                ("path_policy", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class rrt_debug_outputs(C.Structure):
@@ -60,6 +61,10 @@ SYMBOLS = [
     ("rrt_sky_create", _i, [_vp, _i, _i, C.POINTER(_ull)]),
     ("rrt_sky_create_from_device", _i, [_vp, _i, _i, C.POINTER(_ull)]),
     ("rrt_sky_destroy", _i, [_ull]),
+    ("rrt_workspace_create", _i, [C.c_size_t, C.POINTER(_i)]),
+    ("rrt_workspace_destroy", _i, [_i]),
+    ("rrt_workspace_stats", _i, [_i, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    ("rrt_workspace_read", _i, [_i, C.c_size_t, C.c_size_t, _vp]),
     ("rrt_launch_raymarch", _i, [_vp, _i, _i, _f, _cam, _ull, _fx, _prm, _vp]),
     ("rrt_launch_raymarch_rows", _i, [_vp, _i, _i, _i, _i, _f, _cam, _ull, _fx, _prm, _vp]),
     ("rrt_launch_raymarch_tiles", _i, [_vp, _i, _i, _i, _i, _i, _f, _cam, _ull, _fx, _prm, _vp]),

@@ -391,10 +391,13 @@ RRT_DEV float dust_density(v3 p, float time) {
 /* ---- radiative transfer of one in-zone sample, raymarcher.cu:67-117 ---- */
 struct Radiance { float r, g, b, t; };
 
-RRT_DEV void accumulate_sample(Radiance& acc, float d_disk, float d_cloud, v3 rel_p, float r, v3 vel,
-                               float h, float spin) {
-    if (!(d_disk > 0.001f || d_cloud > 0.001f)) return;
-    float ex = 0.f, ey = 0.f, ez = 0.f, opacity = 0.f;
+/* Emission (ex, ey, ez) and transmittance of one sample; false when the sample contributes nothing
+ * (raymarcher.cu:71 not taken). */
+RRT_DEV bool sample_emission(float d_disk, float d_cloud, v3 rel_p, float r, v3 vel, float h, float spin,
+                             float& ex, float& ey, float& ez, float& step_trans) {
+    if (!(d_disk > 0.001f || d_cloud > 0.001f)) return false;
+    ex = 0.f; ey = 0.f; ez = 0.f;
+    float opacity = 0.f;
     if (d_disk > 0.001f) {
         float g = redshift_factor(rel_p, vel, spin);
         float T = disk_temperature(r);
@@ -418,12 +421,24 @@ RRT_DEV void accumulate_sample(Radiance& acc, float d_disk, float d_cloud, v3 re
         opacity += d_cloud * kCloudOpacity;
     }
     float d_tau = opacity * h;
-    float step_trans = rrt_expf(-d_tau);
+    step_trans = rrt_expf(-d_tau);
+    return true;
+}
+
+/* Beer-Lambert accumulation of one sample, raymarcher.cu:109-115 */
+RRT_DEV void accumulate_emission(Radiance& acc, float ex, float ey, float ez, float step_trans) {
     float factor = (1.0f - step_trans) * acc.t;
     acc.r += ex * factor;
     acc.g += ey * factor;
     acc.b += ez * factor;
     acc.t *= step_trans;
+}
+
+RRT_DEV void accumulate_sample(Radiance& acc, float d_disk, float d_cloud, v3 rel_p, float r, v3 vel,
+                               float h, float spin) {
+    float ex, ey, ez, s;
+    if (!sample_emission(d_disk, d_cloud, rel_p, r, vel, h, spin, ex, ey, ez, s)) return;
+    accumulate_emission(acc, ex, ey, ez, s);
 }
 
 /* ---- sky lookup (replaces tex2D<float4>, raymarcher.cu:134-146; the filter is the

@@ -62,6 +62,31 @@ rrt_sky_t sky_register(const SkyObject& s) {
     return h;
 }
 
+/* ------------------------------------------------------------------ deferred-sampling workspace
+ * Three-pass path: pass 1 marches the geodesics only and appends the in-medium
+ * sample points of a wavefront, one 64-lane "row" per march step that needs one, to a bump-allocated
+ * pool in HBM; pass 2 evaluates the densities + emission of every row with the whole chip, wherever
+ * the row came from; pass 3 composites each ray's samples in march order and shades the pixel.
+ * The pool is handed out in blocks of kBlockRows rows, and blocks in runs of consecutive blocks whose
+ * length doubles (1, 2, 4 ... kMaxRun) every time a wave comes back for more: one atomic per run (a
+ * single counter saturates near 90 atomics/us) and only ~log2(n) dependent pointer hops when pass 3
+ * walks a heavy wave's samples.  Block layout: kBlockRows x six SoA float[64] planes (p.xyz, vel.xyz in;
+ * ex, ey, ez, transmittance out in planes 0-3), then a trailer {lane mask of each row; in the first
+ * block of a run: start and length of the wave's next run}.  Unused rows keep a zero mask. */
+struct DeferCounters { unsigned next_block, overflow_waves, pad0, pad1; };
+struct WaveHdr { unsigned first_block, n_runs, state, pad; };     /* state: 0 done in pass 1, 1 deferred, 2 overflow */
+constexpr unsigned kMaxRun = 32;
+constexpr unsigned kBlockRows = 8;
+constexpr unsigned kRowData = 6 * 256;
+constexpr unsigned kBlockTrailer = kBlockRows * kRowData;         /* masks[kBlockRows] (u64), then next (u32) */
+constexpr unsigned kBlockBytes = kBlockTrailer + kBlockRows * 8 + 64;
+constexpr unsigned kNoBlock = 0xffffffffu;
+
+struct WorkspaceObject { uint8_t* d_base; size_t bytes; };
+std::mutex g_ws_mu;
+std::unordered_map<int, WorkspaceObject> g_ws;
+int g_ws_next = 1;
+
 /* ------------------------------------------------------------------ kernel arguments */
 struct RowMap {        /* local row -> image row, and where its pixels go */
     int n_local_rows;  /* rows rendered by this launch                               */
@@ -85,6 +110,13 @@ struct FrameArgs {
     int max_steps;
     RowMap rows;
     rrt_debug_outputs dbg;
+    /* deferred-sampling workspace (three-pass path), all NULL for the single-kernel path */
+    struct DeferCounters* ctr;
+    struct WaveHdr* hdr;
+    float* finals;          /* 4 arrays of n_lanes: vx, vy, vz, code (steps | hit << 31) */
+    size_t n_lanes;
+    uint8_t* sample_blocks;
+    unsigned block_capacity;
 };
 
 /* image row of local row `lr`, and the local output row it is stored at */
@@ -189,40 +221,29 @@ constexpr float kHVac = kStepSize, kHNear = kStepSize * 0.1f, kHDisk = kStepSize
  * A 256-thread workgroup covers a 16x16 pixel block as four 8x8 wave tiles so that the 64 rays of a
  * wavefront stay spatially coherent (similar step counts, similar zone entry).
  */
-template <bool SPIN, bool VOL, bool DEBUG, bool FAST>
-__global__ __launch_bounds__(256) void raymarch_pixels(const FrameArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int lr = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    int y, out_row;
-    if (x >= a.width || !map_row(a.rows, a.height, lr, y, out_row)) return;
+/* radius of the pre-step position exactly as the march sees it (strict: correctly rounded; fast: r2*rsq) */
+template <bool FAST>
+__device__ __forceinline__ void march_radius(v3 rel_p, float& r2, float& r, float& y) {
+    if (FAST) {
+        r2 = dot_fma(rel_p, rel_p);
+        y = __builtin_amdgcn_rsqf(r2);
+        r = r2 * y;
+    } else {
+        r2 = dot(rel_p, rel_p);
+        sqrt_rsq(r2, r, y);
+    }
+    if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {
+        if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
+    }
+}
 
-    float uvx, uvy;
-    v3 p, vel;
-    primary_ray(a, x, y, uvx, uvy, p, vel);
-
-    Radiance acc = {0.f, 0.f, 0.f, 1.0f};
-    bool hit = false;
-    int i = 0;
-
-    /* raymarcher.cu:41-121 */
+/* The whole march of one ray with the media sampled in line: raymarcher.cu:41-121. */
+template <bool SPIN, bool VOL, bool FAST>
+__device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel, Radiance& acc, bool& hit, int& i) {
     for (; i < a.max_steps; ++i) {
         const v3 rel_p = p;                             /* p - MASS_POS, MASS_POS = 0 */
         float r2, r, y;
-        if (FAST) {
-            r2 = dot_fma(rel_p, rel_p);
-            y = __builtin_amdgcn_rsqf(r2);
-            r = r2 * y;
-            if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {
-                if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
-            }
-        } else {
-            r2 = dot(rel_p, rel_p);
-            sqrt_rsq(r2, r, y);
-            if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {
-                if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
-            }
-        }
+        march_radius<FAST>(rel_p, r2, r, y);
         if (r < kEventHorizon * 1.01f) { hit = true; acc.t = 0.0f; break; }
 
         const bool near_bh = r < 18.0f;
@@ -242,7 +263,286 @@ __global__ __launch_bounds__(256) void raymarch_pixels(const FrameArgs a) {
         }
         if (r > 250.0f && dot(rel_p, vel) > 0.0f) { ++i; break; }
     }
+}
+
+/* Workgroup geometry of the per-ray kernels.  A wavefront always covers an 8x8 pixel tile, so its 64 rays
+ * stay spatially coherent (similar step counts, similar zone entry).  RRT_WG_WAVES = 1: one wavefront per
+ * workgroup (a CU slot is released as soon as that wave is done -- no waiting for three siblings);
+ * 4: a 16x16 pixel block per 256-thread workgroup. */
+#ifndef RRT_WG_WAVES
+#define RRT_WG_WAVES 1
+#endif
+constexpr int kWGWaves = RRT_WG_WAVES;
+constexpr int kWGThreads = 64 * kWGWaves;
+constexpr int kWGPixX = kWGWaves == 4 ? 16 : 8, kWGPixY = kWGWaves == 4 ? 16 : 8;
+
+/* Workgroups are dispatched in blockIdx order; the rows through the middle of the frame hold the
+ * longest rays (shadow edge, disk), so row-blocks are visited from the middle outwards: mid, mid+1,
+ * mid-1, ...  Longest-first shortens the tail of a launch; it changes no pixel. */
+__device__ __forceinline__ int row_block() {
+    const int nb = gridDim.y, j = blockIdx.y, mid = (nb - 1) >> 1;
+    return (j & 1) ? mid + ((j + 1) >> 1) : mid - (j >> 1);
+}
+__device__ __forceinline__ bool lane_pixel(const FrameArgs& a, int& x, int& y, int& out_row) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    x = blockIdx.x * kWGPixX + (wave & 1) * 8 + (lane & 7);
+    const int lr = row_block() * kWGPixY + (wave >> 1) * 8 + (lane >> 3);
+    return x < a.width && map_row(a.rows, a.height, lr, y, out_row);
+}
+/* max over the live lanes of a wave; lanes that are not executing contribute 0 */
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned other = (unsigned)__shfl_xor((int)v, o);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_index() {
+    return (blockIdx.y * gridDim.x + blockIdx.x) * (unsigned)kWGWaves + (threadIdx.x >> 6);
+}
+
+/* Single-kernel path: one ray per lane, media sampled in line (reference raymarch_kernel,
+ * src/raymarcher.cu:15-174). */
+template <bool SPIN, bool VOL, bool DEBUG, bool FAST>
+__global__ __launch_bounds__(kWGThreads) void raymarch_pixels(const FrameArgs a) {
+    int x, y, out_row;
+    if (!lane_pixel(a, x, y, out_row)) return;
+    float uvx, uvy;
+    v3 p, vel;
+    primary_ray(a, x, y, uvx, uvy, p, vel);
+    Radiance acc = {0.f, 0.f, 0.f, 1.0f};
+    bool hit = false;
+    int i = 0;
+    march_inline<SPIN, VOL, FAST>(a, p, vel, acc, hit, i);
     shade_and_store<DEBUG>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, i);
+}
+
+/* ---- three-pass path, pass 1: geodesics only; sample points of in-medium steps go to the pool ---- */
+template <bool SPIN, bool FAST>
+__global__ __launch_bounds__(kWGThreads) void march_defer(const FrameArgs a) {
+    int x = 0, y = 0, out_row = 0;
+    const bool valid = lane_pixel(a, x, y, out_row);
+    if (!__any(valid)) return;
+    /* lanes without a pixel stay alive (all 64 lanes take part in the wave-level bookkeeping below);
+     * they march nothing: their loop count starts at max_steps */
+    const int lane = threadIdx.x & 63;
+    float uvx = 0.f, uvy = 0.f;
+    v3 p = mk(1000.f, 0.f, 0.f), vel = mk(0.f, 0.f, 0.f);
+    if (valid) primary_ray(a, x, y, uvx, uvy, p, vel);
+
+    bool hit = false;
+    int i = valid ? 0 : a.max_steps;
+    /* wave-level bookkeeping; identical in every lane that is still marching */
+    unsigned first_block = kNoBlock, n_runs = 0;
+    unsigned run_start = kNoBlock, run_len = 0, run_blk = 0;      /* current run; block run_start + run_blk in use */
+    unsigned used = kBlockRows;                                   /* rows used in the current block */
+    bool overflow = false;
+
+    for (; i < a.max_steps; ++i) {
+        const v3 rel_p = p;
+        float r2, r, yv;
+        march_radius<FAST>(rel_p, r2, r, yv);
+        if (r < kEventHorizon * 1.01f) { hit = true; break; }
+
+        const bool near_bh = r < 18.0f;
+        const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
+        const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
+        const float h = near_bh ? kHNear : (in_disk ? kHDisk : kHVac);
+        const float hh = near_bh ? kHNear * 0.5f : (in_disk ? kHDisk * 0.5f : kHVac * 0.5f);
+        const float h6 = near_bh ? kHNear / 6.0f : (in_disk ? kHDisk / 6.0f : kHVac / 6.0f);
+
+        if (FAST) integrate_rk4_fast<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, yv);
+        else integrate_rk4_r<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, r, yv);
+
+        /* Both density functions return 0 unless the cylindrical radius rc = sqrtf(x*x + 0*0 + z*z) is in
+         * [ISCO, DISK_OUT] (densities.h:21-22, :70-71); only those steps need a sample.  rc comes from
+         * sqrt_rsq, which equals sqrtf bit for bit on [1, 2^64) (self-checked); rc2 < 1 is outside anyway. */
+        unsigned long long need_mask = 0ull;
+        bool need = false;
+        if (__any(in_disk || in_cloud)) {
+            if (in_disk || in_cloud) {
+                const float rc2 = rel_p.x * rel_p.x + 0.0f * 0.0f + rel_p.z * rel_p.z;
+                float rc, rci;
+                sqrt_rsq(rc2, rc, rci);
+                need = rc2 >= 1.0f && !(rc < kIsco || rc > kDiskOut);
+            }
+            need_mask = __ballot(need);
+        }
+        if (need_mask != 0ull) {
+            const int leader = __ffsll((long long)__ballot(1)) - 1;
+            if (used == kBlockRows) {                              /* wave-uniform: next block */
+                if (run_start != kNoBlock && run_blk + 1 < run_len) {
+                    ++run_blk;                                     /* still inside the current run */
+                } else {                                           /* take a new run, twice as long */
+                    const unsigned len = run_len == 0 ? 1u : (run_len * 2 > kMaxRun ? kMaxRun : run_len * 2);
+                    unsigned start = 0;
+                    if (lane == leader) start = atomicAdd(&a.ctr->next_block, len);
+                    start = __builtin_amdgcn_readfirstlane(start);
+                    if (start + len > a.block_capacity) { overflow = true; break; }
+                    if (lane == leader) {                          /* lanes 0-7 may have left the loop already */
+                        for (unsigned b2 = 0; b2 < len; ++b2) {
+                            ulonglong2* m = reinterpret_cast<ulonglong2*>(a.sample_blocks + (size_t)(start + b2) * kBlockBytes +
+                                                                          kBlockTrailer);
+#pragma unroll
+                            for (unsigned k = 0; k < kBlockRows / 2; ++k) m[k] = make_ulonglong2(0ull, 0ull);
+                        }
+                        unsigned* link = reinterpret_cast<unsigned*>(a.sample_blocks + (size_t)start * kBlockBytes +
+                                                                     kBlockTrailer + kBlockRows * 8);
+                        link[0] = kNoBlock; link[1] = 0u;
+                        if (run_start != kNoBlock) {
+                            unsigned* prev = reinterpret_cast<unsigned*>(a.sample_blocks + (size_t)run_start * kBlockBytes +
+                                                                         kBlockTrailer + kBlockRows * 8);
+                            prev[0] = start; prev[1] = len;
+                        }
+                    }
+                    if (first_block == kNoBlock) first_block = start;
+                    run_start = start; run_len = len; run_blk = 0;
+                    ++n_runs;
+                }
+                used = 0;
+            }
+            uint8_t* base = a.sample_blocks + (size_t)(run_start + run_blk) * kBlockBytes;
+            if (need) {
+                float* f = reinterpret_cast<float*>(base + used * kRowData) + lane;
+                f[0] = rel_p.x; f[64] = rel_p.y; f[128] = rel_p.z;
+                f[192] = vel.x; f[256] = vel.y; f[320] = vel.z;
+            }
+            if (lane == leader) reinterpret_cast<unsigned long long*>(base + kBlockTrailer)[used] = need_mask;
+            ++used;
+        }
+        if (r > 250.0f && dot(rel_p, vel) > 0.0f) { ++i; break; }
+    }
+
+    /* wave-level epilogue: all 64 lanes are here */
+    overflow = __any(overflow);
+    const unsigned wid = wave_index();
+    if (overflow) {                                   /* pool exhausted: pass 3 renders this wave in line */
+        if (lane == 0) { a.hdr[wid].state = 2; atomicAdd(&a.ctr->overflow_waves, 1u); }
+        return;
+    }
+    /* lanes that left the loop early hold stale copies of the bookkeeping: the lane that ran longest has
+     * the final run count, and any lane that saw the first allocation has first_block */
+    n_runs = wave_max_u32(n_runs);
+    first_block = ~wave_max_u32(~first_block);
+    if (n_runs == 0) {                              /* no medium touched: finish the pixel here */
+        Radiance acc = {0.f, 0.f, 0.f, hit ? 0.0f : 1.0f};
+        if (valid) shade_and_store<false>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, i);
+        return;                                       /* hdr[wid].state stays 0 (memset) */
+    }
+    const size_t li = (size_t)wid * 64 + lane;
+    a.finals[li] = vel.x;
+    a.finals[a.n_lanes + li] = vel.y;
+    a.finals[2 * a.n_lanes + li] = vel.z;
+    reinterpret_cast<unsigned*>(a.finals)[3 * a.n_lanes + li] = (unsigned)i | (hit ? 0x80000000u : 0u);
+    if (lane == 0) { a.hdr[wid].first_block = first_block; a.hdr[wid].n_runs = n_runs; a.hdr[wid].state = 1; }
+}
+
+/* ---- pass 2: densities + emission of every pooled sample row, grid-stride over the pool ---- */
+template <bool FAST>
+__global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
+    const int lane = threadIdx.x & 63;
+    const unsigned n_blk = min(a.ctr->next_block, a.block_capacity);
+    const unsigned total = n_blk * kBlockRows;
+    const unsigned n_waves = gridDim.x * 4u;
+    for (unsigned row = blockIdx.x * 4u + (threadIdx.x >> 6); row < total; row += n_waves) {
+        uint8_t* blk = a.sample_blocks + (size_t)(row / kBlockRows) * kBlockBytes;
+        const unsigned k = row % kBlockRows;
+        const unsigned long long mask = reinterpret_cast<const unsigned long long*>(blk + kBlockTrailer)[k];
+        if (!((mask >> lane) & 1ull)) continue;
+        float* f = reinterpret_cast<float*>(blk + k * kRowData) + lane;
+        const v3 rel_p = mk(f[0], f[64], f[128]);
+        const v3 vel = mk(f[192], f[256], f[320]);
+        float r2, r, yv;
+        march_radius<FAST>(rel_p, r2, r, yv);
+        const bool near_bh = r < 18.0f;
+        const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
+        const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
+        const float h = near_bh ? kHNear : (in_disk ? kHDisk : kHVac);
+        const float d_disk = in_disk ? accretion_density<true>(rel_p, a.time) : 0.0f;
+        const float d_cloud = in_cloud ? dust_density(rel_p, a.time) : 0.0f;
+        float ex, ey, ez, s;
+        if (!sample_emission(d_disk, d_cloud, rel_p, r, vel, h, a.spin, ex, ey, ez, s)) {
+            ex = 0.f; ey = 0.f; ez = 0.f; s = 1.0f;       /* identity for accumulate_emission */
+        }
+        f[0] = ex; f[64] = ey; f[128] = ez; f[192] = s;
+    }
+}
+
+/* ---- pass 3: composite each ray's samples in march order, then shade; renders overflowed waves in line ---- */
+template <bool SPIN, bool FAST>
+__global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArgs a) {
+    int x, y, out_row;
+    if (!lane_pixel(a, x, y, out_row)) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned wid = wave_index();
+#ifdef RRT_WAVETIME
+    const unsigned long long wt_c0 = __builtin_amdgcn_s_memtime();
+#endif
+    const unsigned state = a.hdr[wid].state;
+    if (state == 0) return;
+    float uvx, uvy;
+    v3 p, vel;
+    primary_ray(a, x, y, uvx, uvy, p, vel);
+    if (state == 2) {
+        Radiance acc = {0.f, 0.f, 0.f, 1.0f};
+        bool hit = false;
+        int i = 0;
+        march_inline<SPIN, true, FAST>(a, p, vel, acc, hit, i);
+        shade_and_store<false>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, i);
+        return;
+    }
+    const size_t li = (size_t)wid * 64 + lane;
+    vel = mk(a.finals[li], a.finals[a.n_lanes + li], a.finals[2 * a.n_lanes + li]);
+    const unsigned code = reinterpret_cast<const unsigned*>(a.finals)[3 * a.n_lanes + li];
+    const bool hit = (code >> 31) != 0;
+    Radiance acc = {0.f, 0.f, 0.f, 1.0f};
+    unsigned run_start = a.hdr[wid].first_block, run_len = 1;
+    const unsigned n_runs = min(a.hdr[wid].n_runs, 4096u);
+    for (unsigned rn = 0; rn < n_runs; ++rn) {
+        const unsigned* link = reinterpret_cast<const unsigned*>(a.sample_blocks + (size_t)run_start * kBlockBytes +
+                                                                 kBlockTrailer + kBlockRows * 8);
+        const unsigned next_start = link[0], next_len = link[1];
+        if (run_len > kMaxRun || run_start + run_len > a.block_capacity) break;    /* never walk outside the pool */
+        /* Blocks of a run are consecutive, so several can be in flight at once: the walk is bound by load
+         * latency (a heavy wave has ~250 blocks), not by arithmetic.  kNB blocks' loads are issued together,
+         * then their rows are accumulated in order. */
+        constexpr unsigned kNB = 4;
+        for (unsigned b = 0; b < run_len; b += kNB) {
+            float e[kNB][kBlockRows][4];
+            unsigned long long m[kNB][kBlockRows];
+            /* unconditional, address-independent loads (rows a lane does not own are read and ignored):
+             * conditional loads would serialise into one memory round trip per row */
+#pragma unroll
+            for (unsigned j = 0; j < kNB; ++j) {
+                const uint8_t* blk = a.sample_blocks + (size_t)(run_start + (b + j < run_len ? b + j : b)) * kBlockBytes;
+                const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(blk + kBlockTrailer);
+#pragma unroll
+                for (unsigned k = 0; k < kBlockRows; ++k) {
+                    m[j][k] = masks[k];
+                    const float* f = reinterpret_cast<const float*>(blk + k * kRowData) + lane;
+                    e[j][k][0] = f[0]; e[j][k][1] = f[64]; e[j][k][2] = f[128]; e[j][k][3] = f[192];
+                }
+            }
+#pragma unroll
+            for (unsigned j = 0; j < kNB; ++j) {
+                const bool live = b + j < run_len;                 /* wave-uniform */
+#pragma unroll
+                for (unsigned k = 0; k < kBlockRows; ++k)
+                    if (live && ((m[j][k] >> lane) & 1ull))
+                        accumulate_emission(acc, e[j][k][0], e[j][k][1], e[j][k][2], e[j][k][3]);
+            }
+        }
+        run_start = next_start; run_len = next_len;
+    }
+    if (hit) acc.t = 0.0f;                                         /* raymarcher.cu:49 */
+#ifdef RRT_WAVETIME
+    const unsigned long long wt_mid = __builtin_amdgcn_s_memtime();
+#endif
+    shade_and_store<false>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, (int)(code & 0x7fffffffu));
+#ifdef RRT_WAVETIME
+    if (lane == 0) a.hdr[wid].pad = (unsigned)((wt_mid - wt_c0) >> 4) | ((unsigned)((__builtin_amdgcn_s_memtime() - wt_mid) >> 8) << 24);
+#endif
 }
 
 /* scatter one shard's tile buffer into the full bottom-up frame */
@@ -397,13 +697,14 @@ int check_common(const void* out, int width, int height, const rrt_camera* cam, 
         if (prm->max_steps < 0 || prm->sky_frac_bits < 0 || prm->sky_frac_bits > 16) return RRT_ERR_INVALID_ARGUMENT;
         if (!(prm->spin == prm->spin)) return RRT_ERR_INVALID_ARGUMENT;
         if (prm->arith_mode != RRT_ARITH_STRICT && prm->arith_mode != RRT_ARITH_FAST) return RRT_ERR_INVALID_ARGUMENT;
-        for (int k = 0; k < 3; ++k)
-            if (prm->reserved[k] != 0) return RRT_ERR_INVALID_ARGUMENT;
+        if (prm->workspace < 0) return RRT_ERR_INVALID_ARGUMENT;
+        if (prm->path_policy < RRT_PATH_AUTO || prm->path_policy > RRT_PATH_THREE_PASS) return RRT_ERR_INVALID_ARGUMENT;
+        if (prm->reserved[0] != 0) return RRT_ERR_INVALID_ARGUMENT;
     }
     return RRT_OK;
 }
 
-int fill_args(FrameArgs& a, bool& vol, bool& fast, void* out, int width, int height, float time, const rrt_camera* cam,
+int fill_args(FrameArgs& a, bool& vol, bool& fast, int& workspace, int& policy, void* out, int width, int height, float time, const rrt_camera* cam,
               rrt_sky_t sky, const rrt_effects* fx, const rrt_params* prm_in) {
     rrt_params prm;
     if (prm_in) prm = *prm_in; else rrt_params_default(&prm);
@@ -424,14 +725,78 @@ int fill_args(FrameArgs& a, bool& vol, bool& fast, void* out, int width, int hei
     memset(&a.dbg, 0, sizeof(a.dbg));
     vol = prm.volumetrics != 0;
     fast = prm.arith_mode == RRT_ARITH_FAST;
+    workspace = prm.workspace;
+    policy = prm.path_policy;
+    a.ctr = nullptr; a.hdr = nullptr; a.finals = nullptr; a.n_lanes = 0; a.sample_blocks = nullptr; a.block_capacity = 0;
     return RRT_OK;
 }
 
-int launch(const FrameArgs& a, bool vol, bool debug, bool fast, hipStream_t st) {
-    dim3 block(256);
-    if (a.rows.n_local_rows == 0) return RRT_OK;
+/* Three-pass launch through a workspace.  Returns RRT_OK after enqueuing, or -1 if the workspace cannot
+ * hold this launch's bookkeeping plus a useful pool (the caller then uses the single-kernel path). */
+int launch_deferred(FrameArgs a, bool fast, const WorkspaceObject& ws, hipStream_t st) {
+    dim3 block(kWGThreads);
+    dim3 grid((a.width + kWGPixX - 1) / kWGPixX, (a.rows.n_local_rows + kWGPixY - 1) / kWGPixY);
+    const size_t n_waves = (size_t)grid.x * grid.y * kWGWaves;
+    const size_t n_lanes = n_waves * 64;
+    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t off_hdr = 256;
+    const size_t off_fin = align(off_hdr + n_waves * sizeof(WaveHdr));
+    const size_t off_rows = align(off_fin + n_lanes * 16);
+    if (ws.bytes < off_rows + (size_t)1024 * kBlockBytes) return -1;
+    size_t cap = (ws.bytes - off_rows) / kBlockBytes;
+    if (cap > 0x0fffffffu) cap = 0x0fffffffu;
+    a.ctr = reinterpret_cast<DeferCounters*>(ws.d_base);
+    a.hdr = reinterpret_cast<WaveHdr*>(ws.d_base + off_hdr);
+    a.finals = reinterpret_cast<float*>(ws.d_base + off_fin);
+    a.n_lanes = n_lanes;
+    a.sample_blocks = ws.d_base + off_rows;
+    a.block_capacity = (unsigned)cap;
+    RRT_HIP(hipMemsetAsync(ws.d_base, 0, off_fin, st));            /* counters + wave headers */
     const bool spin = a.spin != 0.0f;
-    dim3 grid((a.width + 15) / 16, (a.rows.n_local_rows + 15) / 16);
+    if (spin) { if (fast) hipLaunchKernelGGL((march_defer<true, true>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((march_defer<true, false>), grid, block, 0, st, a); }
+    else      { if (fast) hipLaunchKernelGGL((march_defer<false, true>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((march_defer<false, false>), grid, block, 0, st, a); }
+    RRT_HIP(hipGetLastError());
+    if (fast) hipLaunchKernelGGL((eval_sample_rows<true>), dim3(2048), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((eval_sample_rows<false>), dim3(2048), dim3(256), 0, st, a);
+    RRT_HIP(hipGetLastError());
+    if (spin) { if (fast) hipLaunchKernelGGL((composite_and_shade<true, true>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((composite_and_shade<true, false>), grid, block, 0, st, a); }
+    else      { if (fast) hipLaunchKernelGGL((composite_and_shade<false, true>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((composite_and_shade<false, false>), grid, block, 0, st, a); }
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+
+/* When does the three-pass path pay?  It does ~8 % more work than the single kernel, but its longest
+ * wavefront is a bare march (<= ~1.2 ms) instead of a march with every media sample in line (up to ~13 ms
+ * on the bench view).  A launch only feels that pole once its own duration gets close to it, i.e. for
+ * small launches -- one GPU's share of a frame that is spread over many GPUs.  Measured on the 4K bench
+ * frame (profiles/README.md): 1/4 of the frame (2.07 M rays) 11.8 ms in line vs 12.6 ms three-pass;
+ * 1/8 (1.04 M rays) 11.7 ms vs 6.8 ms. */
+constexpr long long kThreePassMaxRays = 1500000;
+
+int launch(const FrameArgs& a, bool vol, bool debug, bool fast, int workspace, int policy, hipStream_t st) {
+    dim3 block(kWGThreads);
+    if (a.rows.n_local_rows == 0) return RRT_OK;
+    if (workspace != 0) {
+        WorkspaceObject ws;
+        {
+            std::lock_guard<std::mutex> lk(g_ws_mu);
+            auto it = g_ws.find(workspace);
+            if (it == g_ws.end()) return RRT_ERR_BAD_HANDLE;
+            ws = it->second;
+        }
+        const long long rays = (long long)a.width * a.rows.n_local_rows;
+        const bool want = policy == RRT_PATH_THREE_PASS || (policy == RRT_PATH_AUTO && rays <= kThreePassMaxRays);
+        if (vol && !debug && want) {
+            int rc = launch_deferred(a, fast, ws, st);
+            if (rc >= 0) return rc;
+        }
+    }
+    const bool spin = a.spin != 0.0f;
+    dim3 grid((a.width + kWGPixX - 1) / kWGPixX, (a.rows.n_local_rows + kWGPixY - 1) / kWGPixY);
 #define RRT_LAUNCH(S, V, D) do { if (fast) hipLaunchKernelGGL((raymarch_pixels<S, V, D, true>), grid, block, 0, st, a); \
                                  else hipLaunchKernelGGL((raymarch_pixels<S, V, D, false>), grid, block, 0, st, a); } while (0)
     if (debug) {
@@ -547,6 +912,59 @@ int rrt_sky_destroy(rrt_sky_t sky) {
     return RRT_OK;
 }
 
+int rrt_workspace_create(size_t bytes, int* out) {
+    if (!out || bytes < (size_t)1 << 20) return RRT_ERR_INVALID_ARGUMENT;
+    WorkspaceObject w{nullptr, bytes};
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&w.d_base), bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(workspace)");
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    *out = g_ws_next++;
+    g_ws.emplace(*out, w);
+    return RRT_OK;
+}
+
+int rrt_workspace_destroy(int id) {
+    WorkspaceObject w;
+    {
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        auto it = g_ws.find(id);
+        if (it == g_ws.end()) return RRT_ERR_BAD_HANDLE;
+        w = it->second;
+        g_ws.erase(it);
+    }
+    hipError_t e = hipFree(w.d_base);
+    if (e != hipSuccess) return hip_fail(e, "hipFree(workspace)");
+    return RRT_OK;
+}
+
+int rrt_workspace_stats(int id, unsigned* rows_used, unsigned* overflow_waves) {
+    WorkspaceObject w;
+    {
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        auto it = g_ws.find(id);
+        if (it == g_ws.end()) return RRT_ERR_BAD_HANDLE;
+        w = it->second;
+    }
+    DeferCounters c;
+    RRT_HIP(hipMemcpy(&c, w.d_base, sizeof(c), hipMemcpyDeviceToHost));
+    if (rows_used) *rows_used = c.next_block * kBlockRows;
+    if (overflow_waves) *overflow_waves = c.overflow_waves;
+    return RRT_OK;
+}
+
+int rrt_workspace_read(int id, size_t offset, size_t bytes, void* host_dst) {
+    WorkspaceObject w;
+    {
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        auto it = g_ws.find(id);
+        if (it == g_ws.end()) return RRT_ERR_BAD_HANDLE;
+        w = it->second;
+    }
+    if (!host_dst || offset > w.bytes || bytes > w.bytes - offset) return RRT_ERR_INVALID_ARGUMENT;
+    RRT_HIP(hipMemcpy(host_dst, w.d_base + offset, bytes, hipMemcpyDeviceToHost));
+    return RRT_OK;
+}
+
 int rrt_launch_raymarch_rows(void* d_out_rows, int width, int height, int y0, int y1, float time,
                              const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx,
                              const rrt_params* prm, void* stream) {
@@ -555,10 +973,11 @@ int rrt_launch_raymarch_rows(void* d_out_rows, int width, int height, int y0, in
     if (y0 < 0 || y1 > height || y0 > y1) return RRT_ERR_INVALID_ARGUMENT;
     FrameArgs a;
     bool vol, fast;
-    rc = fill_args(a, vol, fast, d_out_rows, width, height, time, cam, sky, fx, prm);
+    int wsid, policy;
+    rc = fill_args(a, vol, fast, wsid, policy, d_out_rows, width, height, time, cam, sky, fx, prm);
     if (rc) return rc;
     a.rows = RowMap{y1 - y0, y0, y1 - y0 > 0 ? y1 - y0 : 1, 0, 1};
-    return launch(a, vol, false, fast, static_cast<hipStream_t>(stream));
+    return launch(a, vol, false, fast, wsid, policy, static_cast<hipStream_t>(stream));
 }
 
 int rrt_launch_raymarch(void* d_out_rgba8, int width, int height, float time, const rrt_camera* cam,
@@ -573,11 +992,12 @@ int rrt_launch_raymarch_ex(void* d_out_rgba8, int width, int height, float time,
     if (rc) return rc;
     FrameArgs a;
     bool vol, fast;
-    rc = fill_args(a, vol, fast, d_out_rgba8, width, height, time, cam, sky, fx, prm);
+    int wsid, policy;
+    rc = fill_args(a, vol, fast, wsid, policy, d_out_rgba8, width, height, time, cam, sky, fx, prm);
     if (rc) return rc;
     a.rows = RowMap{height, 0, height, 0, 1};
     if (dbg) a.dbg = *dbg;
-    return launch(a, vol, dbg != nullptr, fast, static_cast<hipStream_t>(stream));
+    return launch(a, vol, dbg != nullptr, fast, wsid, policy, static_cast<hipStream_t>(stream));
 }
 
 int rrt_tile_shard_rows(int height, int tile_rows, int shard, int n_shards, int* rows) {
@@ -595,10 +1015,11 @@ int rrt_launch_raymarch_tiles(void* d_out_tiles, int width, int height, int tile
     if (tile_rows <= 0 || n_shards <= 0 || shard < 0 || shard >= n_shards) return RRT_ERR_INVALID_ARGUMENT;
     FrameArgs a;
     bool vol, fast;
-    rc = fill_args(a, vol, fast, d_out_tiles, width, height, time, cam, sky, fx, prm);
+    int wsid, policy;
+    rc = fill_args(a, vol, fast, wsid, policy, d_out_tiles, width, height, time, cam, sky, fx, prm);
     if (rc) return rc;
     a.rows = RowMap{shard_rows(height, tile_rows, shard, n_shards), 0, tile_rows, shard, n_shards};
-    return launch(a, vol, false, fast, static_cast<hipStream_t>(stream));
+    return launch(a, vol, false, fast, wsid, policy, static_cast<hipStream_t>(stream));
 }
 
 int rrt_assemble_tiles(void* d_frame, const void* d_tiles, int width, int height, int tile_rows, int shard,

@@ -30,6 +30,7 @@ def main(argv=None):
     ap.add_argument("--all-effects", action="store_true", help="also enable chromatic aberration (key C)")
     ap.add_argument("--sky", default=None, help="equirectangular image file; default: synthetic sky, seed 1")
     ap.add_argument("--tile-rows", type=int, default=16)
+    ap.add_argument("--workspace-gib", type=int, default=0, help="pool for the three-pass path (0 = single kernel only)")
     ap.add_argument("--out", default=None, help="x.rgba (raw, bottom-up) | dir/ (PPM per frame) | x.mp4 (needs ffmpeg)")
     args = ap.parse_args(argv)
 
@@ -58,8 +59,9 @@ def main(argv=None):
     w, h = args.width, args.height
     tex = rrt.SkyTexture(load_sky(args.sky) if args.sky else synthetic_sky())
     fx = rrt.CameraEffects(useChromaticAberration=bool(args.all_effects))
+    ws = rrt.Workspace(args.workspace_gib << 30) if args.workspace_gib > 0 else None
     prm = rrt.RenderParams(spin=args.spin, volumetrics=0 if args.no_volumetrics else 1,
-                           arith_mode=1 if args.fast else 0)
+                           arith_mode=1 if args.fast else 0, workspace=ws.id if ws else 0)
     path = camera_paths.CameraPath(args.path) if args.path >= 0 else None
     state = {"t": 0.0, "cam": rrt.CameraState.default()}
 

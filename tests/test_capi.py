@@ -50,7 +50,7 @@ def test_defaults_are_the_reference_defaults():
     assert abs(fx.vignetteIntensity - 0.4) < 1e-7 and abs(fx.caAmount - 0.005) < 1e-9
     assert abs(fx.distortionAmount - 0.15) < 1e-7
     p = rrt.RenderParams()
-    assert (p.spin, p.max_steps, p.volumetrics, p.sky_frac_bits) == (0.0, 2000, 1, 8)
+    assert (p.spin, p.max_steps, p.volumetrics, p.sky_frac_bits, p.arith_mode, p.workspace, p.path_policy) == (0.0, 2000, 1, 8, 0, 0, 0)
     with pytest.raises(AttributeError):
         rrt.RenderParams(nonexistent=1)
 

@@ -229,6 +229,51 @@ def test_fast_mode_statistics(ctx):
     assert rel_ok.mean() >= 0.80
 
 
+def test_three_pass_workspace_path_is_byte_identical(ctx):
+    """rrt_params.workspace: march-only pass + pooled sample evaluation + ordered composite must give
+    the bytes of the single-kernel path -- full frames, shards, both arithmetic modes, a=0 and a!=0,
+    and with a pool that is far too small (overflowing wavefronts fall back to the in-line code)."""
+    import torch
+    g, rrt, tex = ctx
+    ws = rrt.Workspace(1 << 30)
+    tiny = rrt.Workspace(16 << 20)
+    try:
+        for (w, h, pos, yaw, pitch, t) in ((320, 180, (0.0, 10.0, -60.0), 0.0, -10.0, 1.0),
+                                           (257, 131, (35.0, 0.8, 10.0), -106.0, -1.2, 12.5),
+                                           (200, 120, (4.2, 0.6, 4.2), -90.0, -5.7, 14.0)):
+            cam = rrt.CameraState.from_angles(pos, yaw, pitch); fx = rrt.CameraEffects(useChromaticAberration=True)
+            for spin in (0.9, 0.0):
+                for mode in (0, 1):
+                    ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+                    rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=spin, arith_mode=mode))
+                    for pool in (ws, tiny):
+                        out = torch.zeros_like(ref)
+                        rrt.launch_raymarch(out, w, h, t, cam, tex, fx,
+                                            rrt.RenderParams(spin=spin, arith_mode=mode, workspace=pool.id, path_policy=2))
+                        torch.cuda.synchronize()
+                        assert torch.equal(out, ref), (w, h, spin, mode, pool.nbytes, pool.stats())
+                    assert ws.stats()["overflow_waves"] == 0 and ws.stats()["rows_used"] > 0
+        assert tiny.stats()["overflow_waves"] > 0           # the small pool really did overflow on the last view
+        # shards through the workspace
+        w, h = 160, 90
+        cam = rrt.CameraState.default(); fx = rrt.CameraEffects()
+        full = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+        rrt.launch_raymarch(full, w, h, 1.0, cam, tex, fx, rrt.RenderParams(spin=0.9))
+        frame = torch.zeros_like(full)
+        prm = rrt.RenderParams(spin=0.9, workspace=ws.id, path_policy=2)
+        for s in range(3):
+            buf = torch.zeros(rrt.tile_shard_rows(h, 8, s, 3) * w * 4, dtype=torch.uint8, device="cuda")
+            rrt.launch_raymarch_tiles(buf, w, h, 8, s, 3, 1.0, cam, tex, fx, prm)
+            rrt.assemble_tiles(frame, buf, w, h, 8, s, 3)
+        torch.cuda.synchronize()
+        assert torch.equal(frame, full)
+        # a bad id is reported, volumetrics-off / debug launches ignore the pool
+        with pytest.raises(rrt.RRTError):
+            rrt.launch_raymarch(frame, w, h, 1.0, cam, tex, fx, rrt.RenderParams(workspace=999))
+    finally:
+        ws.destroy(); tiny.destroy()
+
+
 def test_streams_graph_capture_and_borrowed_sky(ctx, sky):
     """The launch allocates nothing and keeps no state: it runs on a side stream, can be captured into a
     HIP graph and replayed, and accepts a sky that lives in caller-owned device memory."""

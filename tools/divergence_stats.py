@@ -1,7 +1,7 @@
 """dev tool: wave-level waste of the one-ray-per-lane kernel at 4K (needs GPU)."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import relativisticraytracer_amd as rrt
 from relativisticraytracer_amd.sky import synthetic_sky
 w, h = 3840, 2160
