@@ -16,6 +16,15 @@ if ks:
             out[key] = r["Name"]; out[key + "_calls"] = int(r["Calls"]); out[key + "_avg_ms"] = float(r["AverageNs"]) / 1e6
 kt = glob.glob(f"{src}/trace/**/*kernel_trace.csv", recursive=True)
 if kt:
+    # average over the full-frame dispatches only (bench.py also makes one tiny untimed pre-warm launch)
+    rows = [r for r in csv.DictReader(open(kt[0])) if "raymarch" in r["Kernel_Name"]]
+    for fast, key in ((False, "kernel"), (True, "fast_mode_kernel")):
+        sel = [r for r in rows if (", true>(" in r["Kernel_Name"]) == fast]
+        if sel:
+            big = max(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) for r in sel)
+            d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in sel
+                 if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == big]
+            out[key + "_calls"] = len(d); out[key + "_avg_ms"] = sum(d) / len(d)
     for r in csv.DictReader(open(kt[0])):
         if "raymarch" in r["Kernel_Name"] and ", true>(" not in r["Kernel_Name"]:
             out["vgpr"] = int(r["VGPR_Count"]); out["sgpr"] = int(r["SGPR_Count"]); out["lds"] = int(r["LDS_Block_Size"])
@@ -27,8 +36,10 @@ for name in ("fetch", "write", "sq"):
         continue
     acc = {}
     n = {}
-    for r in csv.DictReader(open(cs[0])):
-        if "raymarch" not in r["Kernel_Name"] or ", true>(" in r["Kernel_Name"]:
+    allrows = [r for r in csv.DictReader(open(cs[0])) if "raymarch" in r["Kernel_Name"] and ", true>(" not in r["Kernel_Name"]]
+    big = max((int(r["Grid_Size"]) for r in allrows), default=0)
+    for r in allrows:
+        if int(r["Grid_Size"]) != big:      # skip bench.py's tiny pre-warm launch
             continue
         acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         n[r["Counter_Name"]] = n.get(r["Counter_Name"], 0) + 1
