@@ -74,7 +74,7 @@ rrt_sky_t sky_register(const SkyObject& s) {
  * ex, ey, ez, transmittance out in planes 0-3), then a trailer {lane mask of each row; in the first
  * block of a run: start and length of the wave's next run}.  Unused rows keep a zero mask. */
 struct DeferCounters { unsigned next_block, overflow_waves, pad0, pad1; };
-struct WaveHdr { unsigned first_block, n_runs, state, pad; };     /* state: 0 done in pass 1, 1 deferred, 2 overflow */
+struct WaveHdr { unsigned first_block, n_runs, state, pad; };     /* state: 1 marched (n_runs may be 0), 2 overflow */
 constexpr unsigned kMaxRun = 32;
 constexpr unsigned kBlockRows = 8;
 constexpr unsigned kRowData = 6 * 256;
@@ -319,17 +319,18 @@ __global__ __launch_bounds__(kWGThreads) void raymarch_pixels(const FrameArgs a)
 }
 
 /* ---- three-pass path, pass 1: geodesics only; sample points of in-medium steps go to the pool ---- */
+/* amdgpu_num_sgpr(80): gfx950 admits 8 waves per SIMD only up to 80 SGPRs (7 for 82-96); this loop needs
+ * the occupancy (measured: 4 waves/SIMD is 15 % slower than 8). */
 template <bool SPIN, bool FAST>
-__global__ __launch_bounds__(kWGThreads) void march_defer(const FrameArgs a) {
+__global__ __launch_bounds__(kWGThreads) __attribute__((amdgpu_num_sgpr(80))) void march_defer(const FrameArgs a) {
     int x = 0, y = 0, out_row = 0;
     const bool valid = lane_pixel(a, x, y, out_row);
     if (!__any(valid)) return;
     /* lanes without a pixel stay alive (all 64 lanes take part in the wave-level bookkeeping below);
      * they march nothing: their loop count starts at max_steps */
     const int lane = threadIdx.x & 63;
-    float uvx = 0.f, uvy = 0.f;
     v3 p = mk(1000.f, 0.f, 0.f), vel = mk(0.f, 0.f, 0.f);
-    if (valid) primary_ray(a, x, y, uvx, uvy, p, vel);
+    if (valid) { float uvx, uvy; primary_ray(a, x, y, uvx, uvy, p, vel); }
 
     bool hit = false;
     int i = valid ? 0 : a.max_steps;
@@ -425,11 +426,8 @@ __global__ __launch_bounds__(kWGThreads) void march_defer(const FrameArgs a) {
      * the final run count, and any lane that saw the first allocation has first_block */
     n_runs = wave_max_u32(n_runs);
     first_block = ~wave_max_u32(~first_block);
-    if (n_runs == 0) {                              /* no medium touched: finish the pixel here */
-        Radiance acc = {0.f, 0.f, 0.f, hit ? 0.0f : 1.0f};
-        if (valid) shade_and_store<false>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, i);
-        return;                                       /* hdr[wid].state stays 0 (memset) */
-    }
+    /* terminal state of every ray; pass 3 shades all pixels (keeping the sky / post-FX code and its scalar
+     * operands out of this kernel keeps it at 8 waves per SIMD) */
     const size_t li = (size_t)wid * 64 + lane;
     a.finals[li] = vel.x;
     a.finals[a.n_lanes + li] = vel.y;
@@ -480,7 +478,6 @@ __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArg
     const unsigned long long wt_c0 = __builtin_amdgcn_s_memtime();
 #endif
     const unsigned state = a.hdr[wid].state;
-    if (state == 0) return;
     float uvx, uvy;
     v3 p, vel;
     primary_ray(a, x, y, uvx, uvy, p, vel);
