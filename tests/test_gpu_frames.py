@@ -274,6 +274,41 @@ def test_three_pass_workspace_path_is_byte_identical(ctx):
         ws.destroy(); tiny.destroy()
 
 
+def test_three_pass_full_size_and_heavy_view(ctx):
+    """The pool at scale: the whole 4K bench frame (2.6 M rows, runs of up to 32 blocks) and a disk-skimming
+    1080p view where single wavefronts own ~2000 rows; then the same heavy view through a pool that is too
+    small, so that a large part of the wavefronts take the overflow route."""
+    import torch
+    g, rrt, tex = ctx
+    fx = rrt.CameraEffects()
+    big = rrt.Workspace(6 << 30)
+    small = rrt.Workspace(192 << 20)
+    try:
+        for (w, h, cam, t, pool) in ((3840, 2160, rrt.CameraState.default(), 1.0, big),
+                                     (1920, 1080, rrt.CameraState.from_angles((4.2, 0.6, 4.2), -90.0, -5.7), 14.0, big),
+                                     (1920, 1080, rrt.CameraState.from_angles((4.2, 0.6, 4.2), -90.0, -5.7), 14.0, small)):
+            ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+            rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9))
+            out = torch.zeros_like(ref)
+            rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, workspace=pool.id, path_policy=2))
+            torch.cuda.synchronize()
+            st = pool.stats()
+            assert torch.equal(out, ref), (w, h, st)
+            if pool is small:
+                assert st["overflow_waves"] > 100
+            else:
+                assert st["overflow_waves"] == 0 and st["rows_used"] > 100000
+        # auto policy: a full 4K frame stays on the single kernel (pool untouched), an eighth of it does not
+        w, h = 3840, 2160
+        prm = rrt.RenderParams(spin=0.9, workspace=big.id)
+        buf = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+        rrt.launch_raymarch_tiles(buf, w, h, 16, 3, 8, 1.0, rrt.CameraState.default(), tex, fx, prm)
+        torch.cuda.synchronize()
+        assert 0 < big.stats()["rows_used"] < 600000
+    finally:
+        big.destroy(); small.destroy()
+
+
 def test_streams_graph_capture_and_borrowed_sky(ctx, sky):
     """The launch allocates nothing and keeps no state: it runs on a side stream, can be captured into a
     HIP graph and replayed, and accepts a sky that lives in caller-owned device memory."""
