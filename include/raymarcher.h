@@ -15,7 +15,8 @@
  * an inline call into the C ABI of include/rrt.h.  Like the reference's
  * launcher (src/raymarcher.cu:176-180) it is asynchronous on the null stream,
  * returns void and reports nothing; use rrt_launch_raymarch() directly for the
- * status code, a stream, or run-time scene parameters (spin, volumetrics).
+ * status code, a stream, run-time scene parameters (spin, volumetrics) or your
+ * own workspace.
  *
  * `CameraEffects` is taken from the reference's own
  * camera_effects/camera_settings.h when that header is on the include path
@@ -85,7 +86,15 @@ inline void launch_raymarch(uchar4* d_out, int w, int h, float time, CameraState
     c.forward[0] = cam.forward.x; c.forward[1] = cam.forward.y; c.forward[2] = cam.forward.z;
     c.right[0] = cam.right.x;     c.right[1] = cam.right.y;     c.right[2] = cam.right.z;
     c.up[0] = cam.up.x;           c.up[1] = cam.up.y;           c.up[2] = cam.up.z;
-    (void)rrt_launch_raymarch(d_out, w, h, time, &c, skyboxTex, &fx, /*prm=*/nullptr, /*stream=*/nullptr);
+    /* The reference's operating point (a 1000x700 window, src/main.cpp:467) is a small launch, where the
+     * three-pass path is ~3x faster; it needs a pool, which this wrapper takes from
+     * the library's per-device default (2 GiB, allocated on the first call).  Without a pool the single
+     * kernel is used -- same pixels either way. */
+    rrt_params prm;
+    rrt_params_default(&prm);
+    int ws = 0;
+    if (rrt_default_workspace((size_t)2 << 30, &ws) == RRT_OK) prm.workspace = ws;
+    (void)rrt_launch_raymarch(d_out, w, h, time, &c, skyboxTex, &fx, &prm, /*stream=*/nullptr);
 }
 
 #endif /* RRT_RAYMARCHER_COMPAT_H */

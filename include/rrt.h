@@ -137,9 +137,13 @@ int rrt_sky_destroy(rrt_sky_t sky);
 /* ---- workspace of the three-pass path (rrt_params.workspace): a caller-owned HBM pool, so that a
  *      launch still allocates nothing.  One workspace serves one stream at a time.  ~1.5 KB per
  *      wave-step that touches the media (handed out in blocks of 8); the 4K bench frame uses ~4 GB.  If the pool runs out, the
- *      affected wavefronts are rendered by the in-line code instead (same result, slower). ---- */
+ *      rays it ran out under are finished by the in-line code from where they stopped (same result,
+ *      slower). ---- */
 int rrt_workspace_create(size_t bytes, int* out_id);
 int rrt_workspace_destroy(int id);
+/* a process-wide pool for the current device, created on first use with `bytes_if_absent` bytes; for
+ * single-stream callers such as the reference's render loop (used by include/raymarcher.h) */
+int rrt_default_workspace(size_t bytes_if_absent, int* out_id);
 /* after a launch has completed: rows used and wavefronts that fell back (synchronous read) */
 int rrt_workspace_stats(int id, unsigned* rows_used, unsigned* overflow_waves);
 /* inspection: copy `bytes` of the pool starting at `offset` to host memory (synchronous) */

@@ -63,6 +63,7 @@ SYMBOLS = [
     ("rrt_sky_destroy", _i, [_ull]),
     ("rrt_workspace_create", _i, [C.c_size_t, C.POINTER(_i)]),
     ("rrt_workspace_destroy", _i, [_i]),
+    ("rrt_default_workspace", _i, [C.c_size_t, C.POINTER(_i)]),
     ("rrt_workspace_stats", _i, [_i, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     ("rrt_workspace_read", _i, [_i, C.c_size_t, C.c_size_t, _vp]),
     ("rrt_launch_raymarch", _i, [_vp, _i, _i, _f, _cam, _ull, _fx, _prm, _vp]),

@@ -74,7 +74,7 @@ rrt_sky_t sky_register(const SkyObject& s) {
  * ex, ey, ez, transmittance out in planes 0-3), then a trailer {lane mask of each row; in the first
  * block of a run: start and length of the wave's next run}.  Unused rows keep a zero mask. */
 struct DeferCounters { unsigned next_block, overflow_waves, pad0, pad1; };
-struct WaveHdr { unsigned first_block, n_runs, state, pad; };     /* state: 1 marched (n_runs may be 0), 2 overflow */
+struct WaveHdr { unsigned first_block, n_runs, state, pad; };     /* state: 1 marched, 2 marched until the pool ran out */
 constexpr unsigned kMaxRun = 32;
 constexpr unsigned kBlockRows = 8;
 constexpr unsigned kRowData = 6 * 256;
@@ -113,7 +113,7 @@ struct FrameArgs {
     /* deferred-sampling workspace (three-pass path), all NULL for the single-kernel path */
     struct DeferCounters* ctr;
     struct WaveHdr* hdr;
-    float* finals;          /* 4 arrays of n_lanes: vx, vy, vz, code (steps | hit << 31) */
+    float* finals;          /* 7 arrays of n_lanes: vx, vy, vz, code (steps | hit << 31 | resume << 30), px, py, pz */
     size_t n_lanes;
     uint8_t* sample_blocks;
     unsigned block_capacity;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kWGThreads) __attribute__((amdgpu_num_sgpr(80))) vo
     unsigned first_block = kNoBlock, n_runs = 0;
     unsigned run_start = kNoBlock, run_len = 0, run_blk = 0;      /* current run; block run_start + run_blk in use */
     unsigned used = kBlockRows;                                   /* rows used in the current block */
-    bool overflow = false;
+    bool overflow = false;                                        /* this lane stopped because the pool is full */
 
     for (; i < a.max_steps; ++i) {
         const v3 rel_p = p;
@@ -353,14 +353,14 @@ __global__ __launch_bounds__(kWGThreads) __attribute__((amdgpu_num_sgpr(80))) vo
         const float hh = near_bh ? kHNear * 0.5f : (in_disk ? kHDisk * 0.5f : kHVac * 0.5f);
         const float h6 = near_bh ? kHNear / 6.0f : (in_disk ? kHDisk / 6.0f : kHVac / 6.0f);
 
-        if (FAST) integrate_rk4_fast<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, yv);
-        else integrate_rk4_r<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, r, yv);
-
         /* Both density functions return 0 unless the cylindrical radius rc = sqrtf(x*x + 0*0 + z*z) is in
          * [ISCO, DISK_OUT] (densities.h:21-22, :70-71); only those steps need a sample.  rc comes from
-         * sqrt_rsq, which equals sqrtf bit for bit on [1, 2^64) (self-checked); rc2 < 1 is outside anyway. */
+         * sqrt_rsq, which equals sqrtf bit for bit on [1, 2^64) (self-checked); rc2 < 1 is outside anyway.
+         * The row is reserved BEFORE the step is taken: if the pool is full the lane stops here with its
+         * pre-step state intact, and pass 3 resumes it with the media sampled in line. */
         unsigned long long need_mask = 0ull;
         bool need = false;
+        float* row_f = nullptr;
         if (__any(in_disk || in_cloud)) {
             if (in_disk || in_cloud) {
                 const float rc2 = rel_p.x * rel_p.x + 0.0f * 0.0f + rel_p.z * rel_p.z;
@@ -404,36 +404,43 @@ __global__ __launch_bounds__(kWGThreads) __attribute__((amdgpu_num_sgpr(80))) vo
                 used = 0;
             }
             uint8_t* base = a.sample_blocks + (size_t)(run_start + run_blk) * kBlockBytes;
-            if (need) {
-                float* f = reinterpret_cast<float*>(base + used * kRowData) + lane;
-                f[0] = rel_p.x; f[64] = rel_p.y; f[128] = rel_p.z;
-                f[192] = vel.x; f[256] = vel.y; f[320] = vel.z;
-            }
             if (lane == leader) reinterpret_cast<unsigned long long*>(base + kBlockTrailer)[used] = need_mask;
+            row_f = reinterpret_cast<float*>(base + used * kRowData) + lane;
             ++used;
+        }
+
+        if (FAST) integrate_rk4_fast<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, yv);
+        else integrate_rk4_r<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, r, yv);
+
+        if (need) {                                                /* pre-step position, post-step velocity */
+            row_f[0] = rel_p.x; row_f[64] = rel_p.y; row_f[128] = rel_p.z;
+            row_f[192] = vel.x; row_f[256] = vel.y; row_f[320] = vel.z;
         }
         if (r > 250.0f && dot(rel_p, vel) > 0.0f) { ++i; break; }
     }
 
     /* wave-level epilogue: all 64 lanes are here */
-    overflow = __any(overflow);
     const unsigned wid = wave_index();
-    if (overflow) {                                   /* pool exhausted: pass 3 renders this wave in line */
-        if (lane == 0) { a.hdr[wid].state = 2; atomicAdd(&a.ctr->overflow_waves, 1u); }
-        return;
-    }
+    const bool any_overflow = __any(overflow);
     /* lanes that left the loop early hold stale copies of the bookkeeping: the lane that ran longest has
      * the final run count, and any lane that saw the first allocation has first_block */
     n_runs = wave_max_u32(n_runs);
     first_block = ~wave_max_u32(~first_block);
-    /* terminal state of every ray; pass 3 shades all pixels (keeping the sky / post-FX code and its scalar
-     * operands out of this kernel keeps it at 8 waves per SIMD) */
+    /* terminal (or, on overflow, resumable) state of every ray; pass 3 shades all pixels -- keeping the sky
+     * and post-FX code with its scalar operands out of this kernel keeps it at 8 waves per SIMD */
     const size_t li = (size_t)wid * 64 + lane;
     a.finals[li] = vel.x;
     a.finals[a.n_lanes + li] = vel.y;
     a.finals[2 * a.n_lanes + li] = vel.z;
-    reinterpret_cast<unsigned*>(a.finals)[3 * a.n_lanes + li] = (unsigned)i | (hit ? 0x80000000u : 0u);
-    if (lane == 0) { a.hdr[wid].first_block = first_block; a.hdr[wid].n_runs = n_runs; a.hdr[wid].state = 1; }
+    reinterpret_cast<unsigned*>(a.finals)[3 * a.n_lanes + li] =
+        (unsigned)i | (hit ? 0x80000000u : 0u) | (overflow ? 0x40000000u : 0u);
+    a.finals[4 * a.n_lanes + li] = p.x;
+    a.finals[5 * a.n_lanes + li] = p.y;
+    a.finals[6 * a.n_lanes + li] = p.z;
+    if (lane == 0) {
+        a.hdr[wid].first_block = first_block; a.hdr[wid].n_runs = n_runs; a.hdr[wid].state = any_overflow ? 2u : 1u;
+        if (any_overflow) atomicAdd(&a.ctr->overflow_waves, 1u);
+    }
 }
 
 /* ---- pass 2: densities + emission of every pooled sample row, grid-stride over the pool ---- */
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
     }
 }
 
-/* ---- pass 3: composite each ray's samples in march order, then shade; renders overflowed waves in line ---- */
+/* ---- pass 3: composite each ray's samples in march order, resume rays the pool ran out under, shade ---- */
 template <bool SPIN, bool FAST>
 __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArgs a) {
     int x, y, out_row;
@@ -481,18 +488,10 @@ __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArg
     float uvx, uvy;
     v3 p, vel;
     primary_ray(a, x, y, uvx, uvy, p, vel);
-    if (state == 2) {
-        Radiance acc = {0.f, 0.f, 0.f, 1.0f};
-        bool hit = false;
-        int i = 0;
-        march_inline<SPIN, true, FAST>(a, p, vel, acc, hit, i);
-        shade_and_store<false>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, i);
-        return;
-    }
     const size_t li = (size_t)wid * 64 + lane;
     vel = mk(a.finals[li], a.finals[a.n_lanes + li], a.finals[2 * a.n_lanes + li]);
     const unsigned code = reinterpret_cast<const unsigned*>(a.finals)[3 * a.n_lanes + li];
-    const bool hit = (code >> 31) != 0;
+    bool hit = (code >> 31) != 0;
     Radiance acc = {0.f, 0.f, 0.f, 1.0f};
     unsigned run_start = a.hdr[wid].first_block, run_len = 1;
     const unsigned n_runs = min(a.hdr[wid].n_runs, 4096u);
@@ -532,11 +531,18 @@ __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArg
         }
         run_start = next_start; run_len = next_len;
     }
+    int steps = (int)(code & 0x3fffffffu);
+    if (state == 2 && (code & 0x40000000u)) {
+        /* the pool ran out under this ray at step `steps`: carry on from its saved pre-step state with the
+         * media sampled in line -- the samples composited above come first, exactly as in the single kernel */
+        p = mk(a.finals[4 * a.n_lanes + li], a.finals[5 * a.n_lanes + li], a.finals[6 * a.n_lanes + li]);
+        march_inline<SPIN, true, FAST>(a, p, vel, acc, hit, steps);
+    }
     if (hit) acc.t = 0.0f;                                         /* raymarcher.cu:49 */
 #ifdef RRT_WAVETIME
     const unsigned long long wt_mid = __builtin_amdgcn_s_memtime();
 #endif
-    shade_and_store<false>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, (int)(code & 0x7fffffffu));
+    shade_and_store<false>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, steps);
 #ifdef RRT_WAVETIME
     if (lane == 0) a.hdr[wid].pad = (unsigned)((wt_mid - wt_c0) >> 4) | ((unsigned)((__builtin_amdgcn_s_memtime() - wt_mid) >> 8) << 24);
 #endif
@@ -738,7 +744,7 @@ int launch_deferred(FrameArgs a, bool fast, const WorkspaceObject& ws, hipStream
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t off_hdr = 256;
     const size_t off_fin = align(off_hdr + n_waves * sizeof(WaveHdr));
-    const size_t off_rows = align(off_fin + n_lanes * 16);
+    const size_t off_rows = align(off_fin + n_lanes * 28);
     if (ws.bytes < off_rows + (size_t)1024 * kBlockBytes) return -1;
     size_t cap = (ws.bytes - off_rows) / kBlockBytes;
     if (cap > 0x0fffffffu) cap = 0x0fffffffu;
@@ -917,6 +923,25 @@ int rrt_workspace_create(size_t bytes, int* out) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     *out = g_ws_next++;
     g_ws.emplace(*out, w);
+    return RRT_OK;
+}
+
+/* One lazily created pool per device for callers that have nowhere to keep one (the C++ drop-in wrapper).
+ * Not for concurrent use from several streams. */
+int rrt_default_workspace(size_t bytes_if_absent, int* out) {
+    if (!out) return RRT_ERR_INVALID_ARGUMENT;
+    static std::mutex mu;
+    static std::unordered_map<int, int> per_device;
+    int dev = 0;
+    RRT_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = per_device.find(dev);
+    if (it != per_device.end()) { *out = it->second; return RRT_OK; }
+    int id = 0;
+    int rc = rrt_workspace_create(bytes_if_absent, &id);
+    if (rc != RRT_OK) return rc;
+    per_device[dev] = id;
+    *out = id;
     return RRT_OK;
 }
 

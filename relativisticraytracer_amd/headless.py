@@ -61,7 +61,8 @@ def main(argv=None):
     fx = rrt.CameraEffects(useChromaticAberration=bool(args.all_effects))
     ws = rrt.Workspace(args.workspace_gib << 30) if args.workspace_gib > 0 else None
     prm = rrt.RenderParams(spin=args.spin, volumetrics=0 if args.no_volumetrics else 1,
-                           arith_mode=1 if args.fast else 0, workspace=ws.id if ws else 0)
+                           arith_mode=1 if args.fast else 0, workspace=ws.id if ws else 0,
+                           path_policy=int(os.environ.get("RRT_PATH_POLICY", "0")))
     path = camera_paths.CameraPath(args.path) if args.path >= 0 else None
     state = {"t": 0.0, "cam": rrt.CameraState.default()}
 
