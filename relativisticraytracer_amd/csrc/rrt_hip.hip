@@ -3,9 +3,18 @@
  *
  * Replaces the reference's only CUDA translation unit, src/raymarcher.cu
  * (raymarch_kernel :15-174 and launch_raymarch :176-180).  Built with
- *   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+ *   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -shared
  * (relativisticraytracer_amd/build.py).  gfx950 only: no other target, no
  * CUDA dual path.
+ *
+ * Kernels
+ *   raymarch_pixels<SPIN,VOL,DEBUG,FAST>   single-kernel path: one ray per lane, media sampled in line
+ *   march_defer / eval_sample_rows / composite_and_shade
+ *                                          three-pass path through a caller-owned workspace
+ *   assemble_tiles_kernel / assemble_all_kernel   scatter gathered row-tile shards into the frame
+ *   k_* / k_selfcheck_*                    array wrappers of the device functions (tests only)
+ * Host
+ *   C ABI of include/rrt.h, sky and workspace registries, camera basis / path playback
  */
 #include <hip/hip_runtime.h>
 
@@ -481,9 +490,6 @@ __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArg
     if (!lane_pixel(a, x, y, out_row)) return;
     const int lane = threadIdx.x & 63;
     const unsigned wid = wave_index();
-#ifdef RRT_WAVETIME
-    const unsigned long long wt_c0 = __builtin_amdgcn_s_memtime();
-#endif
     const unsigned state = a.hdr[wid].state;
     float uvx, uvy;
     v3 p, vel;
@@ -539,13 +545,7 @@ __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArg
         march_inline<SPIN, true, FAST>(a, p, vel, acc, hit, steps);
     }
     if (hit) acc.t = 0.0f;                                         /* raymarcher.cu:49 */
-#ifdef RRT_WAVETIME
-    const unsigned long long wt_mid = __builtin_amdgcn_s_memtime();
-#endif
     shade_and_store<false>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, steps);
-#ifdef RRT_WAVETIME
-    if (lane == 0) a.hdr[wid].pad = (unsigned)((wt_mid - wt_c0) >> 4) | ((unsigned)((__builtin_amdgcn_s_memtime() - wt_mid) >> 8) << 24);
-#endif
 }
 
 /* scatter one shard's tile buffer into the full bottom-up frame */
