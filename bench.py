@@ -236,10 +236,12 @@ def main():
                        "path": ("auto: three-pass below 1.5 M rays per launch, %d GiB pool" % args.workspace_gib) if ws else "single kernel"},
             "roofline": {"bound": "valu", "achieved": round(tops, 3), "peak": round(VALU_PEAK_TOPS, 2),
                          "unit": "TFLOP/s", "frac": round(tops / VALU_PEAK_TOPS, 4), "traffic": traffic,
+                         "frac_of_fma_peak_157.3": round(tops / 157.3, 4),
                          "kernel": "raymarch_pixels", "kernel_ms": round(k_ms, 3),
                          "ops_per_ray": round(opr, 1), "per_ray_means": {k: round(v, 2) for k, v in means.items()},
                          "note": "source-level unfused FP32 ops (SURVEY 8d formula) / HIP-event kernel time; "
-                                 "peak = 256CU x 4SIMD x 32 lanes x 2.4 GHz",
+                                 "peak = 256CU x 4SIMD x 32 lanes x 2.4 GHz = one unfused FP32 op per lane per clock "
+                                 "(the datasheet's 157.3 TFLOP/s counts an FMA as two)",
                          "hbm": {"bound": "hbm", "achieved": round(hbm_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(hbm_gbs / HBM_PEAK_GBS, 6),
                                  "note": "algorithmic 52 B/ray; the path is not HBM-bound"}},
