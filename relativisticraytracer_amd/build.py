@@ -51,8 +51,26 @@ def build_lib(force=False, extra_flags=(), verbose=False):
     return LIB
 
 
+HEADLESS_SRC = os.path.join(CSRC, "rrt_headless.cpp")
+HEADLESS_BIN = os.path.join(LIBDIR, "rrt_headless")
+
+
+def build_headless(force=False):
+    """The C++ headless driver (host code only: g++, links librrt_hip.so and the HIP runtime)."""
+    build_lib()
+    if not force and os.path.exists(HEADLESS_BIN) and os.path.getmtime(HEADLESS_BIN) > max(
+            os.path.getmtime(HEADLESS_SRC), os.path.getmtime(LIB)):
+        return HEADLESS_BIN
+    cmd = ["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", HEADLESS_SRC,
+           "-L" + LIBDIR, "-lrrt_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + LIBDIR + ":/opt/rocm/lib",
+           "-o", HEADLESS_BIN]
+    subprocess.run(cmd, check=True)
+    return HEADLESS_BIN
+
+
 if __name__ == "__main__":
     extra = []
     if "--save-temps" in sys.argv:
         extra += ["-save-temps", "-Rpass-analysis=kernel-resource-usage"]
     print(build_lib(force="--force" in sys.argv or bool(extra), extra_flags=extra, verbose=True))
+    print(build_headless(force="--force" in sys.argv))

@@ -62,3 +62,24 @@ def test_headless_path_playback_equals_manual_frames(tmp_path):
         rrt.launch_raymarch(buf, 96, 54, st, path.camera_at(pt), tex, fx, rrt.RenderParams(spin=0.9))
         torch.cuda.synchronize()
         assert np.array_equal(buf.cpu().numpy().reshape(54, 96, 4), data[k - 1]), k
+
+
+def test_cpp_headless_driver_builds():
+    from relativisticraytracer_amd import build
+    exe = build.build_headless()
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 2
+
+
+@pytest.mark.gpu
+def test_cpp_and_python_drivers_write_the_same_frames(tmp_path):
+    """rrt_headless (C++ over the C ABI) and headless.py render the same 3 frames of path 2."""
+    from relativisticraytracer_amd import build
+    exe = build.build_headless()
+    a, b = tmp_path / "cpp.rgba", tmp_path / "py.rgba"
+    args = ["--width", "128", "--height", "72", "--frames", "3", "--path", "2", "--spin", "0.9", "--all-effects"]
+    subprocess.run([exe] + args + ["--out", str(a)], check=True, capture_output=True)
+    subprocess.run([sys.executable, "-m", "relativisticraytracer_amd.headless"] + args + ["--out", str(b)],
+                   cwd=ROOT, check=True, capture_output=True)
+    assert open(a, "rb").read() == open(b, "rb").read()
