@@ -269,6 +269,12 @@ def sky_sample(dirs, off, sky, frac_bits=8, mode=MATH_LIBM):
     return out
 
 
+def rt_sample(d_disk, d_cloud, p, vel, h, spin, rad, mode=MATH_LIBM):
+    d_disk = _fa(d_disk); d_cloud = _fa(d_cloud); p = _fa(p); vel = _fa(vel); h = _fa(h); rad = _fa(rad).copy()
+    lib().rrto_rt_sample(len(h), _p(d_disk), _p(d_cloud), _p(p), _p(vel), _p(h), _f(spin), int(mode), _p(rad))
+    return rad
+
+
 def math_fn(fn, mode, a, b=None):
     """fn: 0 exp, 1 pow(a,b), 2 sin, 3 cos, 4 atan2(a,b), 5 asin."""
     a = _fa(a); b = _fa(b if b is not None else np.zeros_like(a)); out = np.empty_like(a)

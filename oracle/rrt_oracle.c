@@ -271,6 +271,57 @@ static inline float dust_density(ctx_t* c, f3 p, float time) {
     return base * strands * 12.0f;
 }
 
+/* ---- radiative transfer of one in-zone sample: raymarcher.cu:71-116 ---- */
+static inline int rt_sample(const ctx_t* c, float d_disk, float d_cloud, f3 rel_p, float r, f3 vel, float current_h,
+                            float spin, float* intensity_r, float* intensity_g, float* intensity_b,
+                            float* transmittance) {
+    if (d_disk > 0.001f || d_cloud > 0.001f) {
+        f3 step_emit = mk3(0, 0, 0);
+        float step_opacity = 0;
+
+        if (d_disk > 0.001f) {
+            float g = redshift_factor(c, rel_p, vel, spin);
+            float T = disk_temperature(c, r);
+            float T_norm = m_pow(c, T / DISK_TEMP_REF, 0.5f);
+            float bol_I = m_pow(c, g, 4.0f) * T_norm * d_disk * DISK_LUMINOSITY;
+
+            float color_t = g * m_pow(c, T / DISK_TEMP_REF, 0.4f) * 2.5f;
+            step_emit.x += 1.0f * bol_I;
+            step_emit.y += fminf(0.25f, 0.12f * color_t) * bol_I;
+            step_emit.z += fmaxf(0.0f, 0.01f * (color_t - 2.0f)) * bol_I;
+
+            step_opacity += d_disk * DISK_OPACITY;
+        }
+
+        if (d_cloud > 0.001f) {
+            float g = redshift_factor(c, rel_p, vel, spin);
+            float lighting = 0.5f + 3.0f * m_pow(c, ISCO_RADIUS / fmaxf(r, ISCO_RADIUS), 1.2f);
+            float cloud_I = d_cloud * CLOUD_LUMINOSITY * lighting;
+
+            float shift = smoothstepf(0.7f, 1.3f, g);
+            f3 base_color = mk3(0.60f, 0.65f, 0.80f);
+
+            step_emit.x += base_color.x * cloud_I * lerpf(1.2f, 0.8f, shift);
+            step_emit.y += base_color.y * cloud_I * lerpf(0.8f, 1.1f, shift);
+            step_emit.z += base_color.z * cloud_I * lerpf(0.6f, 1.4f, shift);
+
+            step_opacity += d_cloud * CLOUD_OPACITY;
+        }
+
+        float d_tau = step_opacity * current_h;
+        float step_trans = m_exp(c, -d_tau);
+        float factor = (1.0f - step_trans) * (*transmittance);
+
+        *intensity_r += step_emit.x * factor;
+        *intensity_g += step_emit.y * factor;
+        *intensity_b += step_emit.z * factor;
+
+        *transmittance *= step_trans;
+        return 1;
+    }
+    return 0;
+}
+
 /* ---- post_processing.h:13-31 ---- */
 static inline f3 apply_vignette(f3 color, float uvx, float uvy, float intensity) {
     float d = length3(sub3(mk3(uvx, uvy, 0), mk3(0.5f, 0.5f, 0)));
@@ -407,50 +458,8 @@ static void trace_pixel(const rrto_camera* cam, const rrto_effects* fx, const rr
             float d_disk = (in_disk_zone && prm->volumetrics) ? accretion_density(&c, rel_p, time) : 0.0f;
             float d_cloud = (in_cloud_zone && prm->volumetrics) ? dust_density(&c, rel_p, time) : 0.0f;
 
-            if (d_disk > 0.001f || d_cloud > 0.001f) {
-                f3 step_emit = mk3(0, 0, 0);
-                float step_opacity = 0;
-                n_samples++;
-
-                if (d_disk > 0.001f) {
-                    float g = redshift_factor(&c, rel_p, vel, spin);
-                    float T = disk_temperature(&c, r);
-                    float T_norm = m_pow(&c, T / DISK_TEMP_REF, 0.5f);
-                    float bol_I = m_pow(&c, g, 4.0f) * T_norm * d_disk * DISK_LUMINOSITY;
-
-                    float color_t = g * m_pow(&c, T / DISK_TEMP_REF, 0.4f) * 2.5f;
-                    step_emit.x += 1.0f * bol_I;
-                    step_emit.y += fminf(0.25f, 0.12f * color_t) * bol_I;
-                    step_emit.z += fmaxf(0.0f, 0.01f * (color_t - 2.0f)) * bol_I;
-
-                    step_opacity += d_disk * DISK_OPACITY;
-                }
-
-                if (d_cloud > 0.001f) {
-                    float g = redshift_factor(&c, rel_p, vel, spin);
-                    float lighting = 0.5f + 3.0f * m_pow(&c, ISCO_RADIUS / fmaxf(r, ISCO_RADIUS), 1.2f);
-                    float cloud_I = d_cloud * CLOUD_LUMINOSITY * lighting;
-
-                    float shift = smoothstepf(0.7f, 1.3f, g);
-                    f3 base_color = mk3(0.60f, 0.65f, 0.80f);
-
-                    step_emit.x += base_color.x * cloud_I * lerpf(1.2f, 0.8f, shift);
-                    step_emit.y += base_color.y * cloud_I * lerpf(0.8f, 1.1f, shift);
-                    step_emit.z += base_color.z * cloud_I * lerpf(0.6f, 1.4f, shift);
-
-                    step_opacity += d_cloud * CLOUD_OPACITY;
-                }
-
-                float d_tau = step_opacity * current_h;
-                float step_trans = m_exp(&c, -d_tau);
-                float factor = (1.0f - step_trans) * transmittance;
-
-                intensity_r += step_emit.x * factor;
-                intensity_g += step_emit.y * factor;
-                intensity_b += step_emit.z * factor;
-
-                transmittance *= step_trans;
-            }
+            if (rt_sample(&c, d_disk, d_cloud, rel_p, r, vel, current_h, spin,
+                          &intensity_r, &intensity_g, &intensity_b, &transmittance)) n_samples++;
         }
 
         if (r > 250.0f && dot3(rel_p, vel) > 0) { i++; break; }
@@ -603,6 +612,17 @@ void rrto_sky_sample(int n, const float* dir, float off, const uint8_t* sky, int
                      int frac_bits, int mode, float* out) {
     ctx_t c = {mode, 0, 0}; for (int i = 0; i < n; ++i) sample_sky(&c, ld3(dir, i), off, sky, sw, sh, frac_bits, out + 4 * i);
 }
+/* one radiative-transfer sample per element: rad (r,g,b,T) is updated in place */
+void rrto_rt_sample(int n, const float* d_disk, const float* d_cloud, const float* p, const float* vel,
+                    const float* h, float spin, int mode, float* rad) {
+    ctx_t c = {mode, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        f3 rp = ld3(p, i);
+        rt_sample(&c, d_disk[i], d_cloud[i], rp, length3(rp), ld3(vel, i), h[i], spin,
+                  rad + 4 * i, rad + 4 * i + 1, rad + 4 * i + 2, rad + 4 * i + 3);
+    }
+}
+
 void rrto_math(int fn, int mode, int n, const float* a, const float* b, float* out) {
     ctx_t c = {mode, 0, 0};
     for (int i = 0; i < n; ++i) {

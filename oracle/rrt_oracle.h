@@ -91,6 +91,9 @@ void rrto_vignette(int n, const float* rgb, const float* uv, float intensity, fl
 void rrto_bloom(int n, const float* rgb, float threshold, float* out);
 void rrto_sky_sample(int n, const float* dir, float off, const uint8_t* sky, int sw, int sh,
                      int frac_bits, int math_mode, float* out_rgba);
+/* radiative transfer of one sample per element (raymarcher.cu:71-116); rad = 4 floats (I_rgb, T) in/out */
+void rrto_rt_sample(int n, const float* d_disk, const float* d_cloud, const float* p, const float* vel,
+                    const float* h, float spin, int math_mode, float* rad);
 /* portable-vs-libm probes: fn 0 exp, 1 pow(x,y), 2 sin, 3 cos, 4 atan2(x=y_arg,y=x_arg), 5 asin */
 void rrto_math(int fn, int math_mode, int n, const float* a, const float* b, float* out);
 
