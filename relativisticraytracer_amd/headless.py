@@ -34,7 +34,6 @@ def main(argv=None):
     ap.add_argument("--out", default=None, help="x.rgba (raw, bottom-up) | dir/ (PPM per frame) | x.mp4 (needs ffmpeg)")
     args = ap.parse_args(argv)
 
-    import numpy as np
     import torch
     import relativisticraytracer_amd as rrt
     from relativisticraytracer_amd import camera_paths, sharding, sinks

@@ -1,7 +1,6 @@
 """Host-side camera path code against the reference's own src/camera_paths.cpp
 (tests/golden/camera_ref.npz, produced from oracle/_ref/libref_camera.so)."""
 import numpy as np
-import pytest
 
 from conftest import same_bits
 

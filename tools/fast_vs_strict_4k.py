@@ -1,6 +1,6 @@
 """dev tool (GPU): deviation of RRT_ARITH_FAST from the strict path on full 4K frames, several views."""
 import sys
-import numpy as np, torch
+import torch
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import relativisticraytracer_amd as rrt
 from relativisticraytracer_amd.sky import synthetic_sky

@@ -1,5 +1,5 @@
 """Quick kernel timing (dev tool): python tools/quick_time.py [w h spin vol reps]"""
-import sys, time
+import sys
 import torch
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import relativisticraytracer_amd as rrt
