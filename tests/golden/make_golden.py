@@ -2,7 +2,7 @@
 """Generate the golden fixtures under tests/golden/.
 
 Runs in the BUILD CONTAINER only (it needs /root/reference for the unit
-vectors).  Two kinds of fixture, kept in separate files so their provenance
+vectors).  Fixtures of different provenance are kept in separate files so their provenance
 stays clear:
 
   units_ref.npz      inputs + outputs of the REFERENCE's own device functions
@@ -11,6 +11,10 @@ stays clear:
                      oracle restatement to the reference, bit for bit.
   camera_ref.npz     catmull_rom / lerp_angle samples and the three keyframe
                      tables from the reference's src/camera_paths.cpp.
+  camera_states_restatement.npz
+                     camera bases along the three paths at recording frames 1/75/150/
+                     225/300, from the build's C++ restatement of main.cpp:141-203
+                     (main.cpp is unbuildable here): regression pins only.
   frames_oracle.npz  small frames rendered by the oracle RESTATEMENT (both math
                      modes).  The reference cannot render a frame here (its
                      kernel needs nvcc), so these are regression pins of the
@@ -116,6 +120,17 @@ def make_camera():
         out[f"path{idx}_name"] = np.frombuffer(name.encode(), np.uint8)
     np.savez_compressed(os.path.join(HERE, "camera_ref.npz"), **out)
     print("camera_ref.npz:", len(out), "arrays")
+    # Camera states along the three paths at recording frames {1, 75, 150, 225, 300} (dt = 1/24 accumulated in
+    # binary32).  getInterpolatedState / getCUDAStateFrom live in src/main.cpp, which cannot be built
+    # here, so these come from the build's own C++ restatement (rrt_path_camera_at): regression pins only.
+    from relativisticraytracer_amd import camera_paths as cp
+    states = {}
+    for idx, path in enumerate(cp.paths()):
+        for k in (1, 75, 150, 225, 300):
+            _, pt = cp.recording_clock(k)
+            states[f"path{idx}_frame{k}"] = path.camera_at(pt).as_array()
+    np.savez_compressed(os.path.join(HERE, "camera_states_restatement.npz"), **states)
+    print("camera_states_restatement.npz:", len(states), "arrays")
 
 
 # frame cases: name -> (w, h, spin, volumetrics, camera(pos,yaw,pitch), time, effects overrides)
