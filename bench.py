@@ -140,7 +140,10 @@ def main():
     def assemble_all(frame, bufs, stride):
         rrt.assemble_all_tiles(frame, bufs, stride, w, h, R, world)
 
-    fs = sharding.FrameSharder(w, h, R, rank, world, dev, render, assemble, assemble_all=assemble_all)
+    # N > 1: the gather of frame k runs on the communicator's stream under the render of frame k+1; the last
+    # frame is flushed (gathered + assembled) inside the timed region, so K timed steps deliver K frames.
+    fs = sharding.FrameSharder(w, h, R, rank, world, dev, render, assemble, assemble_all=assemble_all,
+                               pipeline=world > 1 and os.environ.get("RRT_NO_PIPELINE", "0") != "1")
 
     # Untimed one-off setup, so that even --warmup 0 times steady-state steps: load the code object with a
     # tiny launch, and bring up the RCCL communicator / its peer-to-peer channels with one small collective
@@ -163,10 +166,12 @@ def main():
 
     for _ in range(args.warmup):
         fs.step(); it["i"] += 1
+    fs.flush()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fs.step(); it["i"] += 1
+    fs.flush()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -232,7 +237,8 @@ def main():
             "config": {"workload": f"{w}x{h} Kerr a={args.spin:g} full volumetric disk+dust, default camera "
                                    f"(0,10,-60) yaw 0 pitch -10, t=1.0, default effects, synthetic 2048x1024 sky seed 1",
                        "rays_per_frame": rays, "max_steps": 2000, "arith_mode": "strict (bit-exact vs oracle)",
-                       "parallelism": f"rowtiles{R}x{world}" if world > 1 else "single",
+                       "parallelism": (f"rowtiles{R}x{world}" + (", gather of frame k under render of k+1" if fs.pipeline else ""))
+                                      if world > 1 else "single",
                        "path": ("auto: three-pass below 1.5 M rays per launch, %d GiB pool" % args.workspace_gib) if ws else "single kernel"},
             "roofline": {"bound": "valu", "achieved": round(tops, 3), "peak": round(VALU_PEAK_TOPS, 2),
                          "unit": "TFLOP/s", "frac": round(tops / VALU_PEAK_TOPS, 4), "traffic": traffic,

@@ -74,9 +74,15 @@ def main(argv=None):
     def assemble_all(frame, bufs, stride):
         rrt.assemble_all_tiles(frame, bufs, stride, w, h, args.tile_rows, world)
 
-    fs = sharding.FrameSharder(w, h, args.tile_rows, rank, world, dev, render, assemble, assemble_all=assemble_all)
+    # with several ranks the gather of frame k runs under the render of frame k+1 (frames arrive one step late)
+    fs = sharding.FrameSharder(w, h, args.tile_rows, rank, world, dev, render, assemble, assemble_all=assemble_all,
+                               pipeline=world > 1)
     sink = sinks.open_sink(args.out, w, h, args.fps) if rank == 0 else None
     host = torch.empty(h * w * 4, dtype=torch.uint8, pin_memory=True) if sink else None
+
+    def deliver(frame):
+        host.copy_(frame, non_blocking=False)
+        sink.write(host.numpy().reshape(h, w, 4))
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -86,9 +92,11 @@ def main(argv=None):
         if path is not None:
             state["cam"] = path.camera_at(path_t)
         frame = fs.step()
-        if sink:
-            host.copy_(frame, non_blocking=False)
-            sink.write(host.numpy().reshape(h, w, 4))
+        if sink and frame is not None:
+            deliver(frame)
+    frame = fs.flush()
+    if sink and fs.pipeline:
+        deliver(frame)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -56,10 +56,18 @@ class FrameSharder:
     render(buf)            fills this rank's tile buffer (a (pad_rows*width*4,) uint8 tensor)
     assemble(frame, buf, shard)   scatters one shard's buffer into the full frame (rank 0 only)
     assemble_all(frame, all_bufs, stride_bytes)   optional: all shards in one launch
+
+    pipeline=True (world > 1) double-buffers the tile and gather buffers and starts the gather of
+    frame k asynchronously, so it runs on the communicator's stream under the render of frame k+1;
+    step() then returns frame k-1 (None on the first call) and flush() the last one.  Ordering rests
+    on the process group's own stream semantics: an async collective starts after the work already
+    queued on the current stream (the render that filled its input), and work.wait() makes the
+    current stream wait for it (before the assemble that reads its output, and before the buffer
+    is rendered into again two steps later).
     """
 
     def __init__(self, width, height, tile_rows, rank, world, device, render, assemble, group=None,
-                 assemble_all=None):
+                 assemble_all=None, pipeline=False, collective_at_world1=False):
         import torch
         self.torch = torch
         self.width, self.height, self.tile_rows = width, height, tile_rows
@@ -67,17 +75,24 @@ class FrameSharder:
         self.pad_rows = max_shard_rows(height, tile_rows, world)
         self.n_bytes = self.pad_rows * width * 4
         self.render, self.assemble, self.assemble_all = render, assemble, assemble_all
-        self.local = torch.zeros(self.n_bytes, dtype=torch.uint8, device=device)
+        # collective_at_world1: run the gather path even on a one-rank group (self-checks of the RCCL calls
+        # on a single GPU); normally a single rank assembles its own buffer directly.
+        self.collective = world > 1 or bool(collective_at_world1)
+        self.pipeline = bool(pipeline) and self.collective
+        self.n_slots = 2 if self.pipeline else 1
+        self.k = 0
+        self.pending = None
+        self.locals = [torch.zeros(self.n_bytes, dtype=torch.uint8, device=device) for _ in range(self.n_slots)]
+        self.local = self.locals[0]
         self.frame = torch.zeros(height * width * 4, dtype=torch.uint8, device=device) if rank == 0 else None
         # one allocation for all shards, so that a single assemble launch can read them (assemble_all)
-        self.gathered_all = (torch.zeros(world * self.n_bytes, dtype=torch.uint8, device=device)
-                             if (rank == 0 and world > 1) else None)
-        self.gathered = (list(self.gathered_all.split(self.n_bytes)) if self.gathered_all is not None else None)
+        self.gathered_alls = [torch.zeros(world * self.n_bytes, dtype=torch.uint8, device=device)
+                              for _ in range(self.n_slots)] if (rank == 0 and self.collective) else None
         # rehearsal mode: a gloo group driving GPU buffers (several ranks sharing one card on a 1-GPU
         # box) stages the gather through host memory; the production backend is nccl (= RCCL).
         self.stage_cpu = False
         self.use_allgather = False
-        if world > 1:
+        if self.collective:
             import torch.distributed as dist
             self.stage_cpu = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
             # Bring the communicator up with the collective the step uses (untimed, once).  `gather` is what
@@ -89,33 +104,64 @@ class FrameSharder:
                             dst=0, group=group)
             except (RuntimeError, NotImplementedError):
                 self.use_allgather = True
-                if self.gathered_all is None:
-                    self.gathered_all = torch.zeros(world * self.n_bytes, dtype=torch.uint8, device=device)
+                if self.gathered_alls is None:
+                    self.gathered_alls = [torch.zeros(world * self.n_bytes, dtype=torch.uint8, device=device)
+                                          for _ in range(self.n_slots)]
                 dist.all_gather_into_tensor(torch.zeros(world * 256, dtype=torch.uint8, device=probe.device), probe,
                                             group=group)
+        self.gathered_all = self.gathered_alls[0] if self.gathered_alls is not None else None
+
+    def _start_gather(self, slot):
+        """Queue the collective for `slot`; returns (work or None, staged host tensors or None)."""
+        import torch.distributed as dist
+        local = self.locals[slot]
+        asyn = self.pipeline
+        if self.use_allgather:
+            return dist.all_gather_into_tensor(self.gathered_alls[slot], local, group=self.group, async_op=asyn), None
+        if self.stage_cpu:
+            loc = local.cpu()
+            got = [self.torch.empty_like(loc) for _ in range(self.world)] if self.rank == 0 else None
+            return dist.gather(loc, got, dst=0, group=self.group, async_op=asyn), got
+        outs = list(self.gathered_alls[slot].split(self.n_bytes)) if self.rank == 0 else None
+        return dist.gather(local, outs, dst=0, group=self.group, async_op=asyn), None
+
+    def _finish(self, work, staged, slot):
+        if work is not None:
+            work.wait()
+        if self.rank != 0:
+            return
+        ga = self.gathered_alls[slot]
+        if staged is not None:
+            for s in range(self.world):
+                ga[s * self.n_bytes:(s + 1) * self.n_bytes].copy_(staged[s])
+        if self.assemble_all is not None:
+            self.assemble_all(self.frame, ga, self.n_bytes)
+        else:
+            for s in range(self.world):
+                self.assemble(self.frame, ga[s * self.n_bytes:(s + 1) * self.n_bytes], s)
 
     def step(self):
-        """Render this rank's tiles, gather to rank 0, assemble there.  Returns the frame on rank 0."""
-        self.render(self.local)
-        if self.world == 1:
-            self.assemble(self.frame, self.local, 0)
+        """Render this rank's tiles, gather to rank 0, assemble there.  Returns the frame on rank 0
+        (pipeline mode: the PREVIOUS step's frame, None on the first call; see flush())."""
+        slot = self.k % self.n_slots
+        self.k += 1
+        self.render(self.locals[slot])
+        if not self.collective:
+            self.assemble(self.frame, self.locals[slot], 0)
             return self.frame
-        import torch.distributed as dist
-        if self.use_allgather:
-            dist.all_gather_into_tensor(self.gathered_all, self.local, group=self.group)
-        elif self.stage_cpu:
-            loc = self.local.cpu()
-            got = [self.torch.empty_like(loc) for _ in range(self.world)] if self.rank == 0 else None
-            dist.gather(loc, got, dst=0, group=self.group)
-            if self.rank == 0:
-                for s in range(self.world):
-                    self.gathered[s].copy_(got[s])
-        else:
-            dist.gather(self.local, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
-        if self.rank == 0:
-            if self.assemble_all is not None:
-                self.assemble_all(self.frame, self.gathered_all, self.n_bytes)
-            else:
-                for s in range(self.world):
-                    self.assemble(self.frame, self.gathered[s], s)
+        work, staged = self._start_gather(slot)
+        if not self.pipeline:
+            self._finish(work, staged, slot)
+            return self.frame
+        prev, self.pending = self.pending, (work, staged, slot)
+        if prev is None:
+            return None
+        self._finish(*prev)
+        return self.frame
+
+    def flush(self):
+        """Complete the frame still in flight (pipeline mode); returns the frame on rank 0."""
+        if self.pending is not None:
+            prev, self.pending = self.pending, None
+            self._finish(*prev)
         return self.frame

@@ -52,7 +52,7 @@ def test_extract_assemble_roundtrip():
         assert np.array_equal(out, frame)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, pipeline):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -64,11 +64,14 @@ def _worker(rank, world, port, q):
     sky = synthetic_sky(256, 128)
     cam = po.camera((0, 10, -60), (0, -0.17364804, 0.9848078), (1, 0, 0), (0, 0.9848078, 0.17364804))
     fx, prm = po.default_effects(), po.default_params(spin=0.9)
+    times = [1.0, 7.5, 12.5]
+    calls = {"n": 0}
 
-    def render(buf):      # oracle stands in for rrt_launch_raymarch_tiles
+    def render(buf):      # oracle stands in for rrt_launch_raymarch_tiles; every frame has its own time
+        t_sim = times[calls["n"]]; calls["n"] += 1
         full = np.zeros((h, w, 4), np.uint8)
         for t, y0, rows in sh.tile_plan(h, R, rank, world):
-            full = po.render(cam, fx, prm, 1.0, w, h, sky, rect=(0, y0, w, y0 + rows), n_threads=1)["rgba8"] | full
+            full = po.render(cam, fx, prm, t_sim, w, h, sky, rect=(0, y0, w, y0 + rows), n_threads=1)["rgba8"] | full
         tiles = sh.extract_numpy(full, w, h, R, rank, world, pad_rows=sh.max_shard_rows(h, R, world))
         buf.copy_(torch.from_numpy(tiles.reshape(-1)))
 
@@ -76,21 +79,34 @@ def _worker(rank, world, port, q):
         f = frame.numpy().reshape(h, w, 4)
         sh.assemble_numpy(f, buf.numpy().reshape(-1, w, 4), w, h, R, shard, world)
 
-    fs = sh.FrameSharder(w, h, R, rank, world, "cpu", render, assemble)
-    frame = fs.step()
+    fs = sh.FrameSharder(w, h, R, rank, world, "cpu", render, assemble, pipeline=pipeline)
+    got = []
+    for k in range(len(times)):
+        f = fs.step()
+        if pipeline and k == 0:
+            assert f is None                     # nothing assembled yet: frame 0 is still in flight
+        elif rank == 0:
+            got.append(f.numpy().copy())
+    f = fs.flush()
+    if pipeline and rank == 0:
+        got.append(f.numpy().copy())
     if rank == 0:
-        ref = po.render(cam, fx, prm, 1.0, w, h, sky, n_threads=2)["rgba8"]
-        q.put(bool(np.array_equal(frame.numpy().reshape(h, w, 4), ref)))
+        ok = len(got) == len(times)
+        for k, t_sim in enumerate(times):
+            ref = po.render(cam, fx, prm, t_sim, w, h, sky, n_threads=2)["rgba8"]
+            ok = ok and bool(np.array_equal(got[k].reshape(h, w, 4), ref))
+        q.put(ok)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gather_world2_gloo_matches_single_render():
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_gather_world2_gloo_matches_single_render(pipeline):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, pipeline)) for r in range(2)]
     for p in procs:
         p.start()
     ok = q.get(timeout=240)
@@ -98,3 +114,34 @@ def test_gather_world2_gloo_matches_single_render():
         p.join(60)
         assert p.exitcode == 0
     assert ok
+
+
+def test_pipelined_step_single_process_gloo():
+    """The collective path on a one-rank gloo group (no subprocesses): frame order and flush()."""
+    import torch
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        w, h, R = 8, 21, 4
+        n = {"i": 0}
+
+        def render(buf):
+            n["i"] += 1
+            buf.fill_(n["i"])
+
+        def assemble(frame, buf, shard):
+            sh.assemble_numpy(frame.numpy().reshape(h, w, 4), buf.numpy().reshape(-1, w, 4), w, h, R, shard, 1)
+
+        for pipeline in (False, True):
+            n["i"] = 0
+            fs = sh.FrameSharder(w, h, R, 0, 1, "cpu", render, assemble, pipeline=pipeline, collective_at_world1=True)
+            seen = []
+            for _ in range(5):
+                f = fs.step()
+                seen.append(None if f is None else int(f[0]))
+            last = int(fs.flush()[0])
+            assert seen == ([None, 1, 2, 3, 4] if pipeline else [1, 2, 3, 4, 5]) and last == 5
+            assert fs.flush() is fs.frame and bool((fs.frame == 5).all())       # idempotent
+    finally:
+        dist.destroy_process_group()

@@ -10,4 +10,29 @@ tt = torch.tensor([1.5], device=dev, dtype=torch.float64); dist.all_reduce(tt, o
 big = torch.zeros(1 * 4096, dtype=torch.uint8, device=dev); dist.all_gather_into_tensor(big, x)
 dist.barrier(); torch.cuda.synchronize()
 print("rccl ok:", bool(torch.equal(out[0], x)), float(tt), bool(torch.equal(big, x)), dist.get_backend())
+
+# the pipelined FrameSharder step (async gather under the next render) through the same group
+import sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import relativisticraytracer_amd as rrt
+from relativisticraytracer_amd import sharding
+from relativisticraytracer_amd.sky import synthetic_sky
+w, h, R = 640, 360, 16
+tex = rrt.SkyTexture(synthetic_sky()); cam = rrt.CameraState.default(); fx = rrt.CameraEffects()
+ws = rrt.Workspace(1 << 30); prm = rrt.RenderParams(spin=0.9, workspace=ws.id)
+times = [1.0, 3.0, 5.0, 7.0]; n = {"i": 0}
+def render(buf):
+    rrt.launch_raymarch_tiles(buf, w, h, R, 0, 1, times[n["i"]], cam, tex, fx, prm); n["i"] += 1
+fs = sharding.FrameSharder(w, h, R, 0, 1, dev, render, None, pipeline=True, collective_at_world1=True,
+                           assemble_all=lambda f, b, st: rrt.assemble_all_tiles(f, b, st, w, h, R, 1))
+got = []
+for k in range(len(times)):
+    f = fs.step()
+    if f is not None: got.append(f.clone())
+got.append(fs.flush().clone())
+ok = len(got) == len(times)
+ref = torch.zeros(h * w * 4, dtype=torch.uint8, device=dev)
+for k, t in enumerate(times):
+    rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9)); torch.cuda.synchronize()
+    ok = ok and bool(torch.equal(ref, got[k]))
+print("pipelined sharder over rccl (1 rank):", ok)
 dist.destroy_process_group()
