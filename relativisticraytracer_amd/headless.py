@@ -58,15 +58,17 @@ def main(argv=None):
     w, h = args.width, args.height
     tex = rrt.SkyTexture(load_sky(args.sky) if args.sky else synthetic_sky())
     fx = rrt.CameraEffects(useChromaticAberration=bool(args.all_effects))
-    ws = rrt.Workspace(args.workspace_gib << 30) if args.workspace_gib > 0 else None
-    prm = rrt.RenderParams(spin=args.spin, volumetrics=0 if args.no_volumetrics else 1,
-                           arith_mode=1 if args.fast else 0, workspace=ws.id if ws else 0,
-                           path_policy=int(os.environ.get("RRT_PATH_POLICY", "0")))
+    # with several ranks two frames are in flight (FrameSharder pipeline mode), each with its own half of the pool
+    n_slots = 2 if world > 1 else 1
+    pools = [rrt.Workspace((args.workspace_gib << 30) // n_slots) for _ in range(n_slots)] if args.workspace_gib > 0 else []
+    prms = [rrt.RenderParams(spin=args.spin, volumetrics=0 if args.no_volumetrics else 1,
+                             arith_mode=1 if args.fast else 0, workspace=pools[j].id if pools else 0,
+                             path_policy=int(os.environ.get("RRT_PATH_POLICY", "0"))) for j in range(n_slots)]
     path = camera_paths.CameraPath(args.path) if args.path >= 0 else None
     state = {"t": 0.0, "cam": rrt.CameraState.default()}
 
-    def render(buf):
-        rrt.launch_raymarch_tiles(buf, w, h, args.tile_rows, rank, world, state["t"], state["cam"], tex, fx, prm)
+    def render(buf, slot):
+        rrt.launch_raymarch_tiles(buf, w, h, args.tile_rows, rank, world, state["t"], state["cam"], tex, fx, prms[slot])
 
     def assemble(frame, buf, shard):
         rrt.assemble_tiles(frame, buf, w, h, args.tile_rows, shard, world)
@@ -74,7 +76,7 @@ def main(argv=None):
     def assemble_all(frame, bufs, stride):
         rrt.assemble_all_tiles(frame, bufs, stride, w, h, args.tile_rows, world)
 
-    # with several ranks the gather of frame k runs under the render of frame k+1 (frames arrive one step late)
+    # with several ranks frame k+1 renders while frame k is gathered and assembled (frames arrive one step late)
     fs = sharding.FrameSharder(w, h, args.tile_rows, rank, world, dev, render, assemble, assemble_all=assemble_all,
                                pipeline=world > 1)
     sink = sinks.open_sink(args.out, w, h, args.fps) if rank == 0 else None

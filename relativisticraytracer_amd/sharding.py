@@ -53,17 +53,22 @@ def extract_numpy(frame, width, height, tile_rows, shard, n_shards, pad_rows=Non
 class FrameSharder:
     """One rank's view of a sharded frame.
 
-    render(buf)            fills this rank's tile buffer (a (pad_rows*width*4,) uint8 tensor)
+    render(buf, slot)      fills this rank's tile buffer (a (pad_rows*width*4,) uint8 tensor); `slot`
+                           (0, or 0/1 in pipeline mode) tells the callback which of its per-slot
+                           resources (e.g. the three-pass pool) belongs to this frame
     assemble(frame, buf, shard)   scatters one shard's buffer into the full frame (rank 0 only)
     assemble_all(frame, all_bufs, stride_bytes)   optional: all shards in one launch
 
-    pipeline=True (world > 1) double-buffers the tile and gather buffers and starts the gather of
-    frame k asynchronously, so it runs on the communicator's stream under the render of frame k+1;
-    step() then returns frame k-1 (None on the first call) and flush() the last one.  Ordering rests
-    on the process group's own stream semantics: an async collective starts after the work already
-    queued on the current stream (the render that filled its input), and work.wait() makes the
-    current stream wait for it (before the assemble that reads its output, and before the buffer
-    is rendered into again two steps later).
+    pipeline=True (world > 1) keeps two frames in flight.  Tile, gather and frame buffers are doubled;
+    frame k is rendered, gathered (async_op: on the communicator's stream) and assembled on stream
+    k mod 2 while frame k+1 is rendered on the other stream, so that (i) the transfer and the
+    collective's latency sit under the next render and (ii) the drain of one frame's kernels -- a
+    rank's share is only a few rounds of wavefronts -- is filled by the next frame's.  step() then
+    returns frame k-1 (None on the first call) and flush() the last one; the returned tensor is valid
+    on the caller's current stream until the second step() after it.
+    Ordering: an async collective starts after the work already queued on the stream it is issued from
+    (the render that filled its input); work.wait() makes that stream wait for it, before the assemble
+    that reads its output and before the slot's buffers are rendered into again, two steps later.
     """
 
     def __init__(self, width, height, tile_rows, rank, world, device, render, assemble, group=None,
@@ -82,9 +87,13 @@ class FrameSharder:
         self.n_slots = 2 if self.pipeline else 1
         self.k = 0
         self.pending = None
+        on_gpu = torch.device(device).type == "cuda"
+        self.streams = [torch.cuda.Stream(device) for _ in range(self.n_slots)] if (self.pipeline and on_gpu) else None
         self.locals = [torch.zeros(self.n_bytes, dtype=torch.uint8, device=device) for _ in range(self.n_slots)]
         self.local = self.locals[0]
-        self.frame = torch.zeros(height * width * 4, dtype=torch.uint8, device=device) if rank == 0 else None
+        self.frames = [torch.zeros(height * width * 4, dtype=torch.uint8, device=device)
+                       for _ in range(self.n_slots)] if rank == 0 else None
+        self.frame = self.frames[0] if rank == 0 else None           # the most recently completed frame
         # one allocation for all shards, so that a single assemble launch can read them (assemble_all)
         self.gathered_alls = [torch.zeros(world * self.n_bytes, dtype=torch.uint8, device=device)
                               for _ in range(self.n_slots)] if (rank == 0 and self.collective) else None
@@ -94,7 +103,7 @@ class FrameSharder:
         self.use_allgather = False
         if self.collective:
             import torch.distributed as dist
-            self.stage_cpu = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
+            self.stage_cpu = dist.get_backend(group) == "gloo" and on_gpu
             # Bring the communicator up with the collective the step uses (untimed, once).  `gather` is what
             # the path needs (only rank 0 assembles); should a backend build lack it, every rank sees the
             # same exception here and the step falls back to an all-gather of the same buffers.
@@ -111,6 +120,15 @@ class FrameSharder:
                                             group=group)
         self.gathered_all = self.gathered_alls[0] if self.gathered_alls is not None else None
 
+    def _on(self, slot):
+        """Context: the slot's stream, ordered after what the caller has queued on the current stream."""
+        if self.streams is None:
+            import contextlib
+            return contextlib.nullcontext()
+        st = self.streams[slot]
+        st.wait_stream(self.torch.cuda.current_stream())
+        return self.torch.cuda.stream(st)
+
     def _start_gather(self, slot):
         """Queue the collective for `slot`; returns (work or None, staged host tensors or None)."""
         import torch.distributed as dist
@@ -126,41 +144,47 @@ class FrameSharder:
         return dist.gather(local, outs, dst=0, group=self.group, async_op=asyn), None
 
     def _finish(self, work, staged, slot):
-        if work is not None:
-            work.wait()
-        if self.rank != 0:
-            return
-        ga = self.gathered_alls[slot]
-        if staged is not None:
-            for s in range(self.world):
-                ga[s * self.n_bytes:(s + 1) * self.n_bytes].copy_(staged[s])
-        if self.assemble_all is not None:
-            self.assemble_all(self.frame, ga, self.n_bytes)
-        else:
-            for s in range(self.world):
-                self.assemble(self.frame, ga[s * self.n_bytes:(s + 1) * self.n_bytes], s)
+        """Wait for the slot's collective and assemble its frame (on the slot's stream)."""
+        with self._on(slot):
+            if work is not None:
+                work.wait()
+            if self.rank == 0:
+                ga, frame = self.gathered_alls[slot], self.frames[slot]
+                if staged is not None:
+                    for s in range(self.world):
+                        ga[s * self.n_bytes:(s + 1) * self.n_bytes].copy_(staged[s])
+                if self.assemble_all is not None:
+                    self.assemble_all(frame, ga, self.n_bytes)
+                else:
+                    for s in range(self.world):
+                        self.assemble(frame, ga[s * self.n_bytes:(s + 1) * self.n_bytes], s)
+        if self.streams is not None:        # the caller reads the frame on its own (current) stream
+            self.torch.cuda.current_stream().wait_stream(self.streams[slot])
+        if self.rank == 0:
+            self.frame = self.frames[slot]
+        return self.frame
 
     def step(self):
         """Render this rank's tiles, gather to rank 0, assemble there.  Returns the frame on rank 0
         (pipeline mode: the PREVIOUS step's frame, None on the first call; see flush())."""
         slot = self.k % self.n_slots
         self.k += 1
-        self.render(self.locals[slot])
         if not self.collective:
+            self.render(self.locals[slot], slot)
             self.assemble(self.frame, self.locals[slot], 0)
             return self.frame
-        work, staged = self._start_gather(slot)
+        with self._on(slot):
+            self.render(self.locals[slot], slot)
+            work, staged = self._start_gather(slot)
         if not self.pipeline:
-            self._finish(work, staged, slot)
-            return self.frame
+            return self._finish(work, staged, slot)
         prev, self.pending = self.pending, (work, staged, slot)
         if prev is None:
             return None
-        self._finish(*prev)
-        return self.frame
+        return self._finish(*prev)
 
     def flush(self):
-        """Complete the frame still in flight (pipeline mode); returns the frame on rank 0."""
+        """Complete the frame still in flight (pipeline mode); returns the last frame on rank 0."""
         if self.pending is not None:
             prev, self.pending = self.pending, None
             self._finish(*prev)

@@ -67,7 +67,7 @@ def _worker(rank, world, port, q, pipeline):
     times = [1.0, 7.5, 12.5]
     calls = {"n": 0}
 
-    def render(buf):      # oracle stands in for rrt_launch_raymarch_tiles; every frame has its own time
+    def render(buf, slot):      # oracle stands in for rrt_launch_raymarch_tiles; every frame has its own time
         t_sim = times[calls["n"]]; calls["n"] += 1
         full = np.zeros((h, w, 4), np.uint8)
         for t, y0, rows in sh.tile_plan(h, R, rank, world):
@@ -126,7 +126,7 @@ def test_pipelined_step_single_process_gloo():
         w, h, R = 8, 21, 4
         n = {"i": 0}
 
-        def render(buf):
+        def render(buf, slot):
             n["i"] += 1
             buf.fill_(n["i"])
 
