@@ -419,3 +419,45 @@ def test_full_size_properties_4k(ctx):
     # the shadow exists and the disk is bright: coarse sanity of the physical picture
     lum = img[..., :3].float().mean(dim=2)
     assert float(lum.max()) > 200 and float((lum < 2).float().mean()) > 0.001
+
+
+def test_pipelined_sharder_over_one_rank_rccl(ctx):
+    """FrameSharder with two frames in flight through a one-rank RCCL group (async gather, wait, assemble on
+    alternating streams): every frame equals the single launch of the same time."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from relativisticraytracer_amd import sharding
+    _, rrt, tex = ctx
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    pools = [rrt.Workspace(256 << 20), rrt.Workspace(256 << 20)]
+    try:
+        w, h, R = 320, 180, 16
+        cam, fx = rrt.CameraState.default(), rrt.CameraEffects()
+        prms = [rrt.RenderParams(spin=0.9, workspace=p.id) for p in pools]
+        times = [1.0, 2.5, 4.0, 5.5, 7.0]
+        n = {"i": 0}
+
+        def render(buf, slot):
+            rrt.launch_raymarch_tiles(buf, w, h, R, 0, 1, times[n["i"]], cam, tex, fx, prms[slot]); n["i"] += 1
+
+        fs = sharding.FrameSharder(w, h, R, 0, 1, "cuda", render, None, pipeline=True, collective_at_world1=True,
+                                   assemble_all=lambda f, b, st: rrt.assemble_all_tiles(f, b, st, w, h, R, 1))
+        got = []
+        for _ in times:
+            f = fs.step()
+            if f is not None:
+                got.append(f.clone())
+        got.append(fs.flush().clone())
+        assert len(got) == len(times)
+        ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+        for k, t in enumerate(times):
+            rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9))
+            torch.cuda.synchronize()
+            assert torch.equal(ref, got[k]), k
+    finally:
+        for p in pools:
+            p.destroy()
+        dist.destroy_process_group()

@@ -83,3 +83,48 @@ def test_cpp_and_python_drivers_write_the_same_frames(tmp_path):
     subprocess.run([sys.executable, "-m", "relativisticraytracer_amd.headless"] + args + ["--out", str(b)],
                    cwd=ROOT, check=True, capture_output=True)
     assert open(a, "rb").read() == open(b, "rb").read()
+
+
+@pytest.mark.gpu
+def test_two_ranks_pipelined_equal_one_rank(tmp_path):
+    """Two ranks sharing the card (gloo rehearsal of the N > 1 path: interleaved tiles, two frames in flight,
+    gather, assemble) write the same 5 frames as one rank."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    a, b = tmp_path / "one.rgba", tmp_path / "two.rgba"
+    args = ["--width", "160", "--height", "90", "--frames", "5", "--path", "0", "--spin", "0.9", "--workspace-gib", "1"]
+    subprocess.run([sys.executable, "-m", "relativisticraytracer_amd.headless"] + args + ["--out", str(a)],
+                   cwd=ROOT, check=True, capture_output=True)
+    env = dict(os.environ, RRT_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        "-m", "relativisticraytracer_amd.headless"] + args + ["--out", str(b)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    meta = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert meta["n_gpus"] == 2 and meta["frames"] == 5
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
+@pytest.mark.gpu
+def test_bench_line_contract():
+    """bench.py at a reduced frame size: one JSON line with the driver's keys, the roofline and the CPU baseline."""
+    r = subprocess.run([sys.executable, "bench.py", "--width", "320", "--height", "180", "--steps", "2", "--warmup", "1",
+                        "--cpu-stride", "4"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 320 * 180 / d["ms_per_step"] / 1e3) < 0.01 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]
