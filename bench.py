@@ -83,7 +83,8 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=16)
     ap.add_argument("--cpu-stride", type=int, default=8, help="CPU baseline sample stride (0 = skip)")
     ap.add_argument("--no-fast", action="store_true", help="skip the informational RRT_ARITH_FAST leg")
-    ap.add_argument("--workspace-gib", type=int, default=6, help="per-rank pool for the three-pass path (N > 1)")
+    ap.add_argument("--workspace-gib", type=int, default=16,
+                    help="per-rank pool for the three-pass path (N > 1), split between the two frames in flight")
     args = ap.parse_args()
 
     import numpy as np

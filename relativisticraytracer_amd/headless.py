@@ -30,7 +30,8 @@ def main(argv=None):
     ap.add_argument("--all-effects", action="store_true", help="also enable chromatic aberration (key C)")
     ap.add_argument("--sky", default=None, help="equirectangular image file; default: synthetic sky, seed 1")
     ap.add_argument("--tile-rows", type=int, default=16)
-    ap.add_argument("--workspace-gib", type=int, default=0, help="pool for the three-pass path (0 = single kernel only)")
+    ap.add_argument("--workspace-gib", type=int, default=8,
+                    help="per-rank pool for the three-pass path, used by launches of <= 1.5 M rays (0 = single kernel only)")
     ap.add_argument("--out", default=None, help="x.rgba (raw, bottom-up) | dir/ (PPM per frame) | x.mp4 (needs ffmpeg)")
     args = ap.parse_args(argv)
 

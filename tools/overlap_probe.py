@@ -10,7 +10,8 @@ tex = rrt.SkyTexture(synthetic_sky()); cam = rrt.CameraState.default(); fx = rrt
 pools = [rrt.Workspace(3 << 30), rrt.Workspace(3 << 30)]
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 bufs = [torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda") for _ in range(2)]
-for n in (8, 4, 2, 1):
+NS = [int(a) for a in sys.argv[1:]] or [8, 4, 2, 1]
+for n in NS:
     for policy, pname in ((0, "auto"),):
         prms = [rrt.RenderParams(spin=0.9, workspace=p.id, path_policy=policy) for p in pools]
         res = {}
