@@ -72,7 +72,8 @@ def use_native_build():
     machine (bench.py's cpu_baseline leg).  Returns True if it could be built and loaded."""
     global _lib
     try:
-        subprocess.run(["make", "-C", HERE, "native"], check=True, stdout=subprocess.DEVNULL,
+        # -B: always recompile here -- a -march=native object made on another machine must never be reused
+        subprocess.run(["make", "-B", "-C", HERE, "native"], check=True, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL)
         nl = C.CDLL(os.path.join(HERE, "librrt_oracle_native.so"))
         nl.rrto_render.restype = _i
