@@ -9,6 +9,8 @@ Bars (north_star: "within 1e-4 relative per channel"):
     rays whose hard density gates (raymarcher.cu:71,76,91; densities.h:85)
     flip on a 1-ulp transcendental difference; their error is bounded too.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -461,3 +463,69 @@ def test_pipelined_sharder_over_one_rank_rccl(ctx):
         for p in pools:
             p.destroy()
         dist.destroy_process_group()
+
+
+def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
+    """Seeded random scenes (camera anywhere from inside the disk to far out, any orientation, spin of either
+    sign, random time / effects / ragged size): the single kernel, the three-pass path with an ample and with
+    a starved pool, and interleaved tile shards must all give the oracle's bytes (portable math mode)."""
+    import torch
+    g, rrt, tex = ctx
+    rng = np.random.default_rng(20261004)
+    ample, starved = rrt.Workspace(512 << 20), rrt.Workspace(13 << 20)     # 13 MiB: the smallest useful pool
+    try:
+        overflowed = 0
+        for case in range(int(os.environ.get("RRT_SWEEP_CASES", "14"))):      # soak: RRT_SWEEP_CASES=300
+            w, h = int(rng.integers(9, 80)), int(rng.integers(5, 48))
+            rad = float(np.exp(rng.uniform(np.log(3.0), np.log(120.0))))
+            ang = float(rng.uniform(0, 2 * np.pi))
+            height = float(rng.normal(0, 0.15) * rad if case % 2 else rng.normal(0, 0.6))
+            pos = (rad * np.cos(ang), height, rad * np.sin(ang))
+            # mostly looking towards the hole (so that the media are in view), jittered; sometimes anywhere
+            yaw_in = np.degrees(np.arctan2(-pos[0], -pos[2]))
+            yaw = float(yaw_in + rng.normal(0, 25)) if case % 5 else float(rng.uniform(-180, 180))
+            pitch = float(np.clip(-np.degrees(np.arctan2(height, rad)) + rng.normal(0, 12), -89, 89))
+            spin = float(rng.choice([0.0, 0.3, 0.9, 0.99, -0.7]))
+            t = float(rng.uniform(0, 30))
+            fxkw = dict(useBloom=bool(rng.integers(2)), useVignette=bool(rng.integers(2)),
+                        useLensDistortion=bool(rng.integers(2)), useChromaticAberration=bool(rng.integers(2)),
+                        bloomThreshold=float(rng.uniform(0.3, 1.2)), bloomIntensity=float(rng.uniform(0, 1)),
+                        vignetteIntensity=float(rng.uniform(0, 0.8)), caAmount=float(rng.uniform(0, 0.02)),
+                        distortionAmount=float(rng.uniform(-0.2, 0.3)))
+            cam = rrt.CameraState.from_angles(pos, yaw, pitch)
+            fx = rrt.CameraEffects(**fxkw)
+            a = cam.as_array()
+            ofx = po.default_effects(use_bloom=int(fxkw["useBloom"]), use_vignette=int(fxkw["useVignette"]),
+                                     use_lens=int(fxkw["useLensDistortion"]), use_ca=int(fxkw["useChromaticAberration"]),
+                                     bloom_threshold=fxkw["bloomThreshold"], bloom_intensity=fxkw["bloomIntensity"],
+                                     vignette_intensity=fxkw["vignetteIntensity"], ca_amount=fxkw["caAmount"],
+                                     distortion_amount=fxkw["distortionAmount"])
+            o = po.render(po.camera(a[0], a[1], a[2], a[3]), ofx,
+                          po.default_params(spin=spin, math_mode=po.MATH_PORTABLE), t, w, h, sky,
+                          want=("rgba8", "ldr", "diag"))
+            tag = (case, w, h, pos, yaw, pitch, spin, t, fxkw)
+            r = g.render_gpu(w, h, spin, 1, cam, t, tex, fx=fx)
+            assert np.array_equal(r["steps"], o["steps"]) and np.array_equal(r["hit"], o["hit"]), tag
+            assert np.array_equal(r["rgba8"], o["rgba8"]) and same_bits(r["ldr"], o["ldr"]), tag
+            want = torch.from_numpy(o["rgba8"].reshape(-1)).cuda()
+            for pool in (ample, starved):
+                out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+                rrt.launch_raymarch(out, w, h, t, cam, tex, fx,
+                                    rrt.RenderParams(spin=spin, workspace=pool.id, path_policy=2))
+                torch.cuda.synchronize()
+                assert torch.equal(out, want), (tag, pool.nbytes, pool.stats())
+            overflowed += starved.stats()["overflow_waves"]
+            n, R = int(rng.integers(2, 6)), int(rng.integers(1, 9))
+            frame = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+            for s in range(n):
+                rows = rrt.tile_shard_rows(h, R, s, n)
+                buf = torch.zeros(max(rows, 1) * w * 4, dtype=torch.uint8, device="cuda")
+                if rows:
+                    rrt.launch_raymarch_tiles(buf, w, h, R, s, n, t, cam, tex, fx,
+                                              rrt.RenderParams(spin=spin, workspace=ample.id, path_policy=2 * (s % 2)))
+                    rrt.assemble_tiles(frame, buf, w, h, R, s, n)
+            torch.cuda.synchronize()
+            assert torch.equal(frame, want), (tag, n, R)
+        assert overflowed > 0          # the starved pool did exercise the overflow route somewhere in the sweep
+    finally:
+        ample.destroy(); starved.destroy()
