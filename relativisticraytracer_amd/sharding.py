@@ -118,6 +118,22 @@ class FrameSharder:
                                           for _ in range(self.n_slots)]
                 dist.all_gather_into_tensor(torch.zeros(world * 256, dtype=torch.uint8, device=probe.device), probe,
                                             group=group)
+            if self.pipeline:
+                # the same collective the pipelined step issues (async_op + wait), once, untimed; if the backend
+                # cannot do it every rank sees the failure here and the sharder runs one frame at a time instead
+                try:
+                    if self.use_allgather:
+                        wk = dist.all_gather_into_tensor(torch.zeros(world * 256, dtype=torch.uint8, device=probe.device),
+                                                         probe, group=group, async_op=True)
+                    else:
+                        wk = dist.gather(probe, [torch.zeros_like(probe) for _ in range(world)] if rank == 0 else None,
+                                         dst=0, group=group, async_op=True)
+                    wk.wait()
+                    if on_gpu:
+                        torch.cuda.synchronize()
+                except (RuntimeError, NotImplementedError, AttributeError):
+                    self.pipeline = False
+                    self.streams = None
         self.gathered_all = self.gathered_alls[0] if self.gathered_alls is not None else None
 
     def _on(self, slot):
