@@ -22,8 +22,11 @@ HEADERS = [os.path.join(CSRC, "rrt_device.h"), os.path.join(CSRC, "rrt_math.h"),
 # -ffp-contract=off: the kernels' arithmetic contract (csrc/rrt_device.h).
 # -fno-slp-vectorize: the SLP vectoriser packs the 3-vector math into v_pk_*_f32 plus a pile of
 # v_mov shuffles; measured 8 % slower than scalar VALU on the march loop (profiles/README.md).
+# -mllvm -enable-post-misched=false: the post-RA machine scheduler's reordering costs the kernels that carry the
+# volumetric code 3-4 % (4K bench frame 44.6 -> 43.3 ms, same bytes; profiles/README.md); the bare march is unaffected.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+               "-fno-gpu-rdc", "-fno-slp-vectorize", "-mllvm", "-enable-post-misched=false",
+               "-Wall", "-Wno-unused-function"]
 
 
 def hipcc_path():

@@ -3,7 +3,7 @@
  *
  * Replaces the reference's only CUDA translation unit, src/raymarcher.cu
  * (raymarch_kernel :15-174 and launch_raymarch :176-180).  Built with
- *   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -shared
+ *   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -enable-post-misched=false -fPIC -shared
  * (relativisticraytracer_amd/build.py).  gfx950 only: no other target, no
  * CUDA dual path.
  *
