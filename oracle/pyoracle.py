@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librrt_oracle.so")
 REF_UNITS_PATH = os.path.join(HERE, "_ref", "libref_units.so")
 REF_CAMERA_PATH = os.path.join(HERE, "_ref", "libref_camera.so")
+REF_FRAMES_PATH = os.path.join(HERE, "_ref", "libref_frames.so")
 
 MATH_LIBM = 0
 MATH_PORTABLE = 1
@@ -260,6 +261,32 @@ def ref_constants():
     out = np.zeros(18, np.float32)
     dll.ref_constants(_p(out))
     return out
+
+
+def ref_frames_available():
+    return os.path.exists(REF_FRAMES_PATH)
+
+
+def ref_render(cam_arr, fx, spin, volumetrics, time, width, height, sky, frac_bits=8, n_threads=0):
+    """One frame from the REFERENCE's own raymarch_kernel body (oracle/_ref/libref_frames.so, build
+    container only; oracle/ref_frames.cpp).  `cam_arr` is the 4x3 basis, `fx` an Effects.
+    Returns {"rgba8": (h, w, 4) uint8 bottom-up, "steps": (h*w,) int32 top-down}."""
+    lib()                                   # librrt_oracle.so (the sampler) must be loaded first
+    dll = C.CDLL(REF_FRAMES_PATH)
+    dll.ref_render.restype = _i
+    cam12 = _fa(np.asarray(cam_arr).reshape(12))
+    flags = np.array([fx.use_bloom, fx.use_vignette, fx.use_ca, fx.use_lens], np.int32)
+    vals = np.array([fx.bloom_threshold, fx.bloom_intensity, fx.vignette_intensity, fx.ca_amount,
+                     fx.distortion_amount], np.float32)
+    sky = np.ascontiguousarray(sky, dtype=np.uint8)
+    rgba8 = np.zeros((height, width, 4), np.uint8)
+    steps = np.zeros(width * height, np.int32)
+    rc = dll.ref_render(_p(cam12), flags.ctypes.data_as(_ip), _p(vals), _f(spin), int(volumetrics), _f(time),
+                        width, height, sky.ctypes.data_as(_u8p), sky.shape[1], sky.shape[0], int(frac_bits),
+                        rgba8.ctypes.data_as(_u8p), steps.ctypes.data_as(_ip), int(n_threads))
+    if rc != 0:
+        raise ValueError("ref_render: bad arguments")
+    return {"rgba8": rgba8, "steps": steps}
 
 
 def sky_sample(dirs, off, sky, frac_bits=8, mode=MATH_LIBM):

@@ -10,9 +10,9 @@
  * definitions; nothing is stubbed.  No reference text is copied here: this
  * file only *calls* the reference's inline functions.
  *
- * Not buildable this way (and therefore not pinned): raymarch_kernel itself
- * (/root/reference/src/raymarcher.cu:15-174 needs tex2D<float4>, blockIdx and
- * the <<<>>> launch, i.e. nvcc) and src/main.cpp (GLFW/GLAD/CUDA-GL interop).
+ * raymarch_kernel itself is built by the sibling harness oracle/ref_frames.cpp
+ * (frame-level fixtures); src/main.cpp (GLFW/GLAD/CUDA-GL interop) is not
+ * buildable here.
  *
  * SPIN_A is a literal macro in the reference (config.h:21, expanded at its use
  * sites geodesics.h:17,41).  To exercise a != 0 from one library the macro is

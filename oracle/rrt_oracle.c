@@ -608,6 +608,11 @@ void rrto_vignette(int n, const float* rgb, const float* uv, float intensity, fl
 void rrto_bloom(int n, const float* rgb, float threshold, float* out) {
     for (int i = 0; i < n; ++i) st3(out, i, bloom_contribution(ld3(rgb, i), threshold));
 }
+/* the bilinear texel filter alone at texture coordinates (tx, ty): the harness of oracle/ref_frames.cpp
+ * uses it as tex2D<float4>, the one piece of the reference kernel that is hardware-defined */
+void rrto_sky_fetch(const uint8_t* sky, int sw, int sh, int frac_bits, float tx, float ty, float* out_rgba) {
+    sky_fetch(sky, sw, sh, frac_bits, tx, ty, out_rgba);
+}
 void rrto_sky_sample(int n, const float* dir, float off, const uint8_t* sky, int sw, int sh,
                      int frac_bits, int mode, float* out) {
     ctx_t c = {mode, 0, 0}; for (int i = 0; i < n; ++i) sample_sky(&c, ld3(dir, i), off, sky, sw, sh, frac_bits, out + 4 * i);

@@ -16,14 +16,18 @@
  *     getDustCloudDensity, smoothstep, lens/vignette/bloom): PINNED bit-exact
  *     to the reference's own headers compiled by g++ (oracle/_ref, built from
  *     /root/reference/include by oracle/Makefile; vectors in tests/golden/).
- *   - the per-pixel pipeline glue (raymarcher.cu:15-174: zone logic, radiative
- *     transfer block, sky lookup, post-FX, tone map) is a restatement that the
- *     reference cannot check: the .cu needs tex2D<>, blockIdx and <<<>>>, which
- *     only nvcc provides, and the reference ships no tests or golden images.
- *     Frame-level parity is therefore "parity unpinned" beyond its pinned
- *     units; see DESIGN.md.
+ *   - the per-pixel pipeline (raymarcher.cu:15-174: loop order, zone / step logic,
+ *     radiative transfer block, sky lookup, composition, post-FX, tone map, row
+ *     flip): PINNED byte for byte -- RGBA8 and per-ray step counts -- to the
+ *     reference's own raymarch_kernel body, compiled by g++ where it lies
+ *     (oracle/ref_frames.cpp + ref_frames_pre.h -> oracle/_ref/libref_frames.so;
+ *     fixtures tests/golden/frames_ref.npz, G1-G5 + two path keyframes + one odd
+ *     view; tests/test_oracle_frames.py).  The harness supplies the launch
+ *     indices and tex2D<float4>, nothing else.
  *   - the sky sampler replaces CUDA's hardware bilinear filter, which the
- *     reference source does not define: "parity unpinned" (DESIGN.md).
+ *     reference source does not define: "parity unpinned" for that one function
+ *     (DESIGN.md section 6); it is also what the reference-kernel harness uses
+ *     as tex2D<float4>.
  *
  * math_mode selects the transcendental library:
  *   RRTO_MATH_LIBM     glibc powf/expf/sinf/cosf/atan2f/asinf (default)
@@ -91,6 +95,8 @@ void rrto_vignette(int n, const float* rgb, const float* uv, float intensity, fl
 void rrto_bloom(int n, const float* rgb, float threshold, float* out);
 void rrto_sky_sample(int n, const float* dir, float off, const uint8_t* sky, int sw, int sh,
                      int frac_bits, int math_mode, float* out_rgba);
+/* the sky texel filter alone (the build's definition of tex2D<float4>) */
+void rrto_sky_fetch(const uint8_t* sky, int sw, int sh, int frac_bits, float tx, float ty, float* out_rgba);
 /* radiative transfer of one sample per element (raymarcher.cu:71-116); rad = 4 floats (I_rgb, T) in/out */
 void rrto_rt_sample(int n, const float* d_disk, const float* d_cloud, const float* p, const float* vel,
                     const float* h, float spin, int math_mode, float* rad);

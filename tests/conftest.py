@@ -34,6 +34,12 @@ def frames_gold():
 
 
 @pytest.fixture(scope="session")
+def frames_ref():
+    """Frames from the reference's OWN raymarch_kernel body (tests/golden/make_golden.py::make_frames_ref)."""
+    return dict(np.load(os.path.join(GOLDEN, "frames_ref.npz")))
+
+
+@pytest.fixture(scope="session")
 def camera_ref():
     return dict(np.load(os.path.join(GOLDEN, "camera_ref.npz")))
 

@@ -15,10 +15,16 @@ stays clear:
                      camera bases along the three paths at recording frames 1/75/150/
                      225/300, from the build's C++ restatement of main.cpp:141-203
                      (main.cpp is unbuildable here): regression pins only.
-  frames_oracle.npz  small frames rendered by the oracle RESTATEMENT (both math
-                     modes).  The reference cannot render a frame here (its
-                     kernel needs nvcc), so these are regression pins of the
-                     restatement, NOT reference outputs.
+  frames_ref.npz     small frames rendered by the REFERENCE's own raymarch_kernel body
+                     (/root/reference/src/raymarcher.cu:15-174 compiled by g++ where it lies,
+                     oracle/ref_frames.cpp + ref_frames_pre.h -> oracle/_ref/libref_frames.so):
+                     RGBA8 and per-ray RK4 step counts.  The only harness-defined arithmetic in
+                     them is the sky texel filter (tex2D<float4>).  These pin
+                     the per-pixel glue of the restatement (loop order, zones, RT block, sky
+                     lookup, post-FX, tone map, row flip) to the reference, byte for byte.
+  frames_oracle.npz  the same small frames rendered by the oracle RESTATEMENT in both math
+                     modes, with per-ray diagnostics the reference kernel does not output
+                     (final p / vel / radiance, float RGB): regression pins + GPU comparison data.
 
     python tests/golden/make_golden.py
 """
@@ -143,6 +149,18 @@ FRAME_CASES = {
 }
 
 
+# reference-kernel frames: G1-G5 plus two camera-path keyframes and one odd-sized random view
+REF_FRAME_CASES = dict(FRAME_CASES)
+REF_FRAME_CASES.update({
+    # path 0 "Gargantua Fly-By" key 1 (camera_paths.cpp:37) and path 2 "Horizon Skimmer" key 2 (:62)
+    "K1": (64, 36, 0.9, 1, ((15.0, 3.0, -30.0), -26.6, -5.1), 6.0, {"use_ca": 1}),
+    "K2": (64, 36, 0.9, 1, ((4.2, 0.6, 4.2), -90.0, -5.7), 14.0, {"use_ca": 1}),
+    "R1": (50, 30, 0.99, 1, ((-22.0, 2.5, 31.0), 143.0, -3.0), 3.25,
+           {"use_bloom": 0, "use_vignette": 1, "vignette_intensity": 0.7, "use_ca": 1, "ca_amount": 0.011,
+            "use_lens": 0}),
+})
+
+
 def frame_camera(spec):
     import relativisticraytracer_amd as rrt
     a = rrt.CameraState.from_angles(*spec).as_array()
@@ -172,8 +190,34 @@ def make_frames():
     print("frames_oracle.npz:", len(out), "arrays")
 
 
+def make_frames_ref():
+    """Frames from the reference's own kernel body (see the module docstring)."""
+    if not po.ref_frames_available():
+        po.build(ref=True)
+    sky = synthetic_sky()
+    out = {}
+    for name, (w, h, spin, vol, camspec, t, fxkw) in REF_FRAME_CASES.items():
+        cam_arr, _ = frame_camera(camspec)
+        fx = po.default_effects(**fxkw)
+        r = po.ref_render(cam_arr, fx, spin, vol, t, w, h, sky)
+        out[f"{name}_camera"] = cam_arr
+        out[f"{name}_scene"] = np.array([w, h, spin, vol, t], np.float64)
+        out[f"{name}_fx_flags"] = np.array([fx.use_bloom, fx.use_vignette, fx.use_ca, fx.use_lens], np.int32)
+        out[f"{name}_fx_vals"] = np.array([fx.bloom_threshold, fx.bloom_intensity, fx.vignette_intensity,
+                                           fx.ca_amount, fx.distortion_amount], np.float32)
+        out[f"{name}_rgba8"] = r["rgba8"]
+        out[f"{name}_steps"] = r["steps"].astype(np.int16)
+        print(name, "reference kernel: mean steps %.1f" % r["steps"].mean())
+    np.savez_compressed(os.path.join(HERE, "frames_ref.npz"), **out)
+    print("frames_ref.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     po.build(ref=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "frames_ref":
+        make_frames_ref()
+        sys.exit(0)
     make_units()
     make_camera()
     make_frames()
+    make_frames_ref()

@@ -2,10 +2,15 @@
 
 What pins what:
   * tests/test_oracle_units.py pins every function the pixel pipeline calls to the reference.
-  * Here: (1) the committed golden frames (regression pins of the restatement, both math modes);
-    (2) the work statistics SURVEY.md 8d measured with the reference's own kernel body
-    (steps/ray, saturated and horizon fractions, noise3D evaluations) -- the only frame-level
-    numbers of the reference that exist; (3) portable-vs-libm closeness.
+  * Here: (0) frames rendered by the REFERENCE's own raymarch_kernel body (frames_ref.npz: the kernel
+    text compiled by g++ where it lies, only tex2D<float4> = the build's sky filter supplied by the
+    harness) -- the restatement must reproduce RGBA8 and per-ray step counts byte for byte, which pins
+    its loop order, zone / step-size logic, radiative-transfer block, composition, post-FX, tone map
+    and row flip to the reference;
+    (1) the committed oracle frames (regression pins of the restatement, both math modes, with the
+    per-ray diagnostics the reference kernel does not output);
+    (2) the work statistics SURVEY.md 8d measured with the reference's own kernel body;
+    (3) portable-vs-libm closeness.
 """
 import numpy as np
 import pytest
@@ -23,6 +28,53 @@ CASES = {   # == tests/golden/make_golden.py FRAME_CASES
 
 def _cam(po, arr):
     return po.camera(arr[0], arr[1], arr[2], arr[3])
+
+
+REF_CASES = ("G1", "G2", "G3", "G4", "G5", "K1", "K2", "R1")
+
+
+def ref_case(po, frames_ref, name, **prm_kw):
+    """(cam, fx, prm, time, w, h) of a frames_ref.npz case, for the oracle."""
+    w, h, spin, vol, t = frames_ref[f"{name}_scene"]
+    fl, fv = frames_ref[f"{name}_fx_flags"], frames_ref[f"{name}_fx_vals"]
+    fx = po.default_effects(use_bloom=int(fl[0]), use_vignette=int(fl[1]), use_ca=int(fl[2]), use_lens=int(fl[3]),
+                            bloom_threshold=float(fv[0]), bloom_intensity=float(fv[1]),
+                            vignette_intensity=float(fv[2]), ca_amount=float(fv[3]), distortion_amount=float(fv[4]))
+    prm = po.default_params(spin=float(np.float32(spin)), volumetrics=int(vol), **prm_kw)
+    return _cam(po, frames_ref[f"{name}_camera"]), fx, prm, float(np.float32(t)), int(w), int(h)
+
+
+@pytest.mark.parametrize("name", REF_CASES)
+def test_restatement_reproduces_the_reference_kernel_frames(po, frames_ref, sky, name):
+    """libm mode (the reference's own math library on a host build) == the reference kernel body:
+    every RGBA8 byte and every per-ray step count."""
+    cam, fx, prm, t, w, h = ref_case(po, frames_ref, name, math_mode=po.MATH_LIBM)
+    r = po.render(cam, fx, prm, t, w, h, sky, want=("rgba8", "diag"))
+    assert np.array_equal(r["rgba8"], frames_ref[f"{name}_rgba8"])
+    assert np.array_equal(r["steps"], frames_ref[f"{name}_steps"].astype(np.int32))
+    assert np.all(r["rgba8"][..., 3] == 255)
+
+
+def test_reference_frames_agree_with_the_committed_oracle_frames(frames_ref, frames_gold):
+    """frames_oracle.npz (restatement, libm) and frames_ref.npz (reference kernel) hold the same G1-G5."""
+    for name in CASES:
+        assert np.array_equal(frames_ref[f"{name}_rgba8"], frames_gold[f"{name}_libm_rgba8"]), name
+        assert np.array_equal(frames_ref[f"{name}_steps"], frames_gold[f"{name}_libm_steps"]), name
+        assert np.array_equal(frames_ref[f"{name}_camera"], frames_gold[f"{name}_camera"]), name
+
+
+@pytest.mark.skipif(not __import__("os").path.exists("/root/reference/src/raymarcher.cu"),
+                    reason="the reference is only present in the build container")
+def test_reference_kernel_build_regenerates_the_fixture(po, frames_ref, sky):
+    """Build container only: re-render one case with oracle/_ref/libref_frames.so and compare with the
+    committed fixture (guards the fixture against drifting from the recipe)."""
+    po.build(ref=True)
+    name = "K2"
+    w, h, spin, vol, t = frames_ref[f"{name}_scene"]
+    _, fx, _, tt, w, h = ref_case(po, frames_ref, name)
+    r = po.ref_render(frames_ref[f"{name}_camera"], fx, float(np.float32(spin)), int(vol), tt, w, h, sky)
+    assert np.array_equal(r["rgba8"], frames_ref[f"{name}_rgba8"])
+    assert np.array_equal(r["steps"], frames_ref[f"{name}_steps"].astype(np.int32))
 
 
 @pytest.mark.parametrize("name", list(CASES))
