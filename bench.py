@@ -72,6 +72,27 @@ def cpu_baseline(width, height, spin, stride, sky):
                       f"({n} rays, {dt:.1f} s wall, oracle/rrt_oracle.c, libm math, OpenMP dynamic rows)"}, means
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (one per GPU,
+    torch.distributed.run, rendezvous on 127.0.0.1) before this process has touched torch or the GPU,
+    relay their output, and return the children's exit status.  Nothing is exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+    for ln in proc.stdout:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +108,9 @@ def main():
                     help="per-rank pool for the three-pass path (N > 1), split between the two frames in flight")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
     import numpy as np
     import torch
     import relativisticraytracer_amd as rrt
@@ -96,15 +120,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (there is no CPU fallback in the product path)")
+    args.gpus = world                                          # under a launcher the launcher's world size rules
     backend = os.environ.get("RRT_DIST_BACKEND", "nccl")        # "gloo": rehearsal on fewer GPUs than ranks
+    n_dev = torch.cuda.device_count()                           # does not initialise the GPU
+    if n_dev == 0:
+        sys.exit("bench.py needs a GPU (there is no CPU fallback in the product path)")
     if backend == "gloo":
-        local_rank %= max(1, torch.cuda.device_count())
+        local_rank %= n_dev
+    elif world > n_dev:
+        sys.exit(f"bench.py: {world} ranks but {n_dev} GPU(s) visible; RCCL needs one GPU per rank "
+                 "(RRT_DIST_BACKEND=gloo rehearses several ranks on one card)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -250,7 +275,9 @@ def main():
                        "rays_per_frame": rays, "max_steps": 2000, "arith_mode": "strict (bit-exact vs oracle)",
                        "parallelism": (f"rowtiles{R}x{world}" + (", two frames in flight (render k+1 overlaps gather/assemble of k)" if fs.pipeline else ""))
                                       if world > 1 else "single",
-                       "path": ("auto: three-pass below 1.5 M rays per launch, %d GiB pool" % args.workspace_gib) if ws else "single kernel"},
+                       "path": ("auto: three-pass below 1.5 M rays per launch, %d GiB pool" % args.workspace_gib) if ws else "single kernel",
+                       "dist_backend": (backend + (" (RCCL)" if backend == "nccl" else " (rehearsal: ranks share a card)")) if world > 1 else None,
+                       "comm_ranks": dist.get_world_size() if world > 1 else 1},
             "roofline": {"bound": "valu", "achieved": round(tops, 3), "peak": round(VALU_PEAK_TOPS, 2),
                          "unit": "TFLOP/s", "frac": round(tops / VALU_PEAK_TOPS, 4), "traffic": traffic,
                          "frac_of_fma_peak_157.3": round(tops / 157.3, 4),

@@ -11,12 +11,13 @@
  *
  * unchanged.  The vector types come from <hip/hip_vector_types.h> (float3 and
  * uchar4 are layout-identical to CUDA's), the texture handle is the 64-bit
- * rrt_sky_t (cudaTextureObject_t is `unsigned long long` too), and the body is
- * an inline call into the C ABI of include/rrt.h.  Like the reference's
- * launcher (src/raymarcher.cu:176-180) it is asynchronous on the null stream,
- * returns void and reports nothing; use rrt_launch_raymarch() directly for the
- * status code, a stream, run-time scene parameters (spin, volumetrics) or your
- * own workspace.
+ * rrt_sky_t (cudaTextureObject_t is `unsigned long long` too), and the function
+ * lives in librrt_hip.so over the C ABI of include/rrt.h.  Like the reference's
+ * launcher (src/raymarcher.cu:176-180) it is asynchronous on the null stream
+ * and returns void (the first failing launch is reported once on stderr); use
+ * rrt_launch_raymarch() directly for the status code or a stream, and
+ * rrt_set_launch_defaults() for run-time scene parameters (spin, volumetrics,
+ * a workspace, a noise table).
  *
  * `CameraEffects` is taken from the reference's own
  * camera_effects/camera_settings.h when that header is on the include path
@@ -68,33 +69,23 @@ typedef rrt_sky_t cudaTextureObject_t;   /* the name src/main.cpp uses for the s
 static_assert(sizeof(CameraState) == sizeof(rrt_camera), "CameraState must stay 4 packed float3");
 static_assert(sizeof(CameraEffects) == sizeof(rrt_effects), "CameraEffects must stay 36 bytes");
 
+/*
+ * launch_raymarch: by default the out-of-line function that librrt_hip.so exports -- like the reference's,
+ * which is defined in src/raymarcher.cu:176-180.  The library carries it twice: under the name this header
+ * produces (HIP's uchar4 is a class template instance) and under the reference's own mangled name
+ * _Z15launch_raymarchP6uchar4iif11CameraStatey13CameraEffects (csrc/rrt_compat.cpp), so that an object file
+ * compiled against the REFERENCE's header with CUDA's vector types links against librrt_hip.so as it is.
+ * Scene parameters the signature has no room for come from rrt_set_launch_defaults(); nothing is allocated.
+ * -DRRT_INLINE_LAUNCH_RAYMARCH gives a header-only inline version instead.
+ */
+#ifdef RRT_INLINE_LAUNCH_RAYMARCH
 inline void launch_raymarch(uchar4* d_out, int w, int h, float time, CameraState cam,
                             cudaTextureObject_t skyboxTex, CameraEffects effects) {
-    rrt_effects fx;
-    rrt_effects_default(&fx);
-    fx.use_bloom = effects.useBloom;
-    fx.bloom_threshold = effects.bloomThreshold;
-    fx.bloom_intensity = effects.bloomIntensity;
-    fx.use_vignette = effects.useVignette;
-    fx.vignette_intensity = effects.vignetteIntensity;
-    fx.use_chromatic_aberration = effects.useChromaticAberration;
-    fx.ca_amount = effects.caAmount;
-    fx.use_lens_distortion = effects.useLensDistortion;
-    fx.distortion_amount = effects.distortionAmount;
-    rrt_camera c;
-    c.pos[0] = cam.pos.x;         c.pos[1] = cam.pos.y;         c.pos[2] = cam.pos.z;
-    c.forward[0] = cam.forward.x; c.forward[1] = cam.forward.y; c.forward[2] = cam.forward.z;
-    c.right[0] = cam.right.x;     c.right[1] = cam.right.y;     c.right[2] = cam.right.z;
-    c.up[0] = cam.up.x;           c.up[1] = cam.up.y;           c.up[2] = cam.up.z;
-    /* The reference's operating point (a 1000x700 window, src/main.cpp:467) is a small launch, where the
-     * three-pass path is ~3x faster; it needs a pool, which this wrapper takes from
-     * the library's per-device default (2 GiB, allocated on the first call).  Without a pool the single
-     * kernel is used -- same pixels either way. */
-    rrt_params prm;
-    rrt_params_default(&prm);
-    int ws = 0;
-    if (rrt_default_workspace((size_t)2 << 30, &ws) == RRT_OK) prm.workspace = ws;
-    (void)rrt_launch_raymarch(d_out, w, h, time, &c, skyboxTex, &fx, &prm, /*stream=*/nullptr);
+    (void)rrt_launch_raymarch_compat(d_out, w, h, time, reinterpret_cast<const float*>(&cam), skyboxTex, &effects);
 }
+#else
+void launch_raymarch(uchar4* d_out, int w, int h, float time, CameraState cam,
+                     cudaTextureObject_t skyboxTex, CameraEffects effects);
+#endif
 
 #endif /* RRT_RAYMARCHER_COMPAT_H */

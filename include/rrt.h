@@ -11,8 +11,9 @@
  *                                      defined src/raymarcher.cu:176-180,
  *                                      called from src/main.cpp:467
  *
- * `include/raymarcher.h` of this repo re-declares it source-compatibly (C++)
- * as an inline wrapper over rrt_launch_raymarch() below; everything here is
+ * `include/raymarcher.h` of this repo re-declares it source-compatibly (C++);
+ * librrt_hip.so exports it as a real C++ symbol, under the reference's own
+ * mangled name too, over rrt_launch_raymarch() below; everything here is
  * plain C: pointers, ints, floats and PODs -- no HIP or torch types.
  *
  * Conventions
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 1
+#define RRT_ABI_VERSION 2
 
 typedef enum {
     RRT_OK = 0,
@@ -93,7 +94,12 @@ typedef struct rrt_params {
     int32_t path_policy;     /* with a workspace: RRT_PATH_AUTO (default) takes the three-pass path for
                                 launches of <= 1.5 M rays (where it is faster) and the single kernel
                                 otherwise; RRT_PATH_SINGLE / RRT_PATH_THREE_PASS force one             */
-    int32_t reserved[1];     /* must be 0 */
+    int32_t noise_table;     /* 0 (default): every noise3D hashes its eight lattice corners arithmetically.
+                                An rrt_noise_table id: the low octaves of the disk / dust noise read the corner
+                                hashes from a precomputed lattice table whenever the 64 rays of a wavefront
+                                share a few lattice cells (4K / 8K frames: most of them) -- same bits, about
+                                half the media cost.  Ignored when `time` lies outside
+                                the table's [0, t_max].                                                   */
 } rrt_params;
 
 #define RRT_PATH_AUTO 0
@@ -118,6 +124,8 @@ typedef struct rrt_debug_outputs {
     float* d_pos;            /* 3 floats/pixel: final position                          */
     float* d_vel;            /* 3 floats/pixel: final velocity                          */
     float* d_rad;            /* 4 floats/pixel: intensity r,g,b and transmittance       */
+    unsigned* d_lut_oob;     /* 1 counter: noise-table reads whose index had to be clamped
+                                (must stay 0: the table box covers every reachable cell)  */
 } rrt_debug_outputs;
 
 /* ---- library ---- */
@@ -141,13 +149,30 @@ int rrt_sky_destroy(rrt_sky_t sky);
  *      slower). ---- */
 int rrt_workspace_create(size_t bytes, int* out_id);
 int rrt_workspace_destroy(int id);
-/* a process-wide pool for the current device, created on first use with `bytes_if_absent` bytes; for
- * single-stream callers such as the reference's render loop (used by include/raymarcher.h) */
-int rrt_default_workspace(size_t bytes_if_absent, int* out_id);
 /* after a launch has completed: rows used and wavefronts that fell back (synchronous read) */
 int rrt_workspace_stats(int id, unsigned* rows_used, unsigned* overflow_waves);
 /* inspection: copy `bytes` of the pool starting at `offset` to host memory (synchronous) */
 int rrt_workspace_read(int id, size_t offset, size_t bytes, void* host_dst);
+
+/* ---- lattice-hash tables for the volumetric noise (rrt_params.noise_table): hash31 (math_utils.h:91-96) of
+ *      every lattice point the low-octave noise3D calls of getAccretionDensity / getDustCloudDensity
+ *      (densities.h:54, :95-128) can reach for 0 <= time <= t_max, computed once on the device by the same
+ *      arithmetic.  Caller-owned like the sky; about 0.2 GB at t_max = 32 s (rrt_noise_table_plan tells).
+ *      Any number of launches / streams may read one table concurrently. ---- */
+int rrt_noise_table_create(float t_max, int* out_id);
+int rrt_noise_table_destroy(int id);
+int rrt_noise_table_info(int id, float* t_max, size_t* bytes, int* boxes12);   /* boxes: x0,y0,z0,nx,ny,nz of the accretion and dust boxes */
+int rrt_noise_table_plan(float t_max, size_t* bytes, int* boxes12);            /* host arithmetic only */
+
+/* ---- parameters of the reference-signature entry point launch_raymarch() (include/raymarcher.h), which has
+ *      no argument for them: spin, max_steps, volumetrics, a workspace, a noise table ...  NULL restores the
+ *      config.h defaults.  Nothing is allocated on the caller's behalf: objects named here are the caller's. ---- */
+int rrt_set_launch_defaults(const rrt_params* prm);
+int rrt_get_launch_defaults(rrt_params* out);
+/* launch_raymarch() with plain C types (what both C++ symbols of that name forward to): cam12 = pos, forward,
+ * right, up; effects36 = the 36 bytes of struct CameraEffects (== rrt_effects); null stream, asynchronous. */
+int rrt_launch_raymarch_compat(void* d_out_rgba8, int width, int height, float time, const float* cam12,
+                               rrt_sky_t sky, const void* effects36);
 
 /* ---- the hot path.  Replaces launch_raymarch, reference include/raymarcher.h:19 /
  *      src/raymarcher.cu:176-180.  Writes width*height RGBA8 pixels, alpha 255,
@@ -202,6 +227,19 @@ int rrt_unit_redshift(int n, const float* d_p, const float* d_vel, float spin, f
 int rrt_unit_math(int fn, int n, const float* d_a, const float* d_b, float* d_out, void* stream);
 int rrt_unit_sky_sample(int n, const float* d_dir, float off, rrt_sky_t sky, int frac_bits,
                         float* d_out_rgba, void* stream);
+int rrt_unit_disk_temperature(int n, const float* d_r, float* d_out, void* stream);          /* densities.h:12-15 */
+int rrt_unit_smoothstep(int n, const float* d_e0, const float* d_e1, const float* d_x, float* d_out, void* stream);
+/* post_processing.h:13-31.  what = 0: apply_lens_distortion (uv[2n] -> out[2n], param = k);
+ * 1: apply_vignette (rgb[3n], uv[2n] -> out[3n], param = intensity); 2: get_bloom_contribution (rgb -> out, param = threshold) */
+int rrt_unit_postfx(int what, int n, const float* d_rgb, const float* d_uv, float param, float* d_out, void* stream);
+/* the radiative-transfer block raymarcher.cu:71-116, one sample per element; d_rad = n x (I_r, I_g, I_b, T), in/out */
+int rrt_unit_rt_sample(int n, const float* d_disk, const float* d_cloud, const float* d_p, const float* d_vel,
+                       const float* d_h, float spin, float* d_rad, void* stream);
+/* noise3D read through a noise table (which = 0 accretion box, 1 dust box); d_counts[0] (may be NULL) counts
+ * reads outside the box.  And both density functions as the render kernels evaluate them (table switches on). */
+int rrt_unit_noise3d_lut(int n, const float* d_p, int table, int which, float* d_out, unsigned* d_counts, void* stream);
+int rrt_unit_media_lut(int n, const float* d_p, float time, int table, float* d_out_disk, float* d_out_dust,
+                       unsigned* d_counts, void* stream);
 
 /* Self-checks of the march loop's hand-rolled correctly-rounded sqrt / divide against the
  * hardware IEEE forms.  d_counters: 4 x uint64 on the device, zeroed by the caller;

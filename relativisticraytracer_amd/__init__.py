@@ -21,7 +21,8 @@ import numpy as np
 from . import _lib
 from ._lib import RRTError, rrt_camera, rrt_debug_outputs, rrt_effects, rrt_params  # noqa: F401
 
-__all__ = ["CameraState", "CameraEffects", "RenderParams", "SkyTexture", "Workspace", "launch_raymarch",
+__all__ = ["CameraState", "CameraEffects", "RenderParams", "SkyTexture", "Workspace", "NoiseTable", "launch_raymarch",
+           "set_launch_defaults", "get_launch_defaults",
            "launch_raymarch_rows", "launch_raymarch_tiles", "assemble_tiles", "assemble_all_tiles",
            "tile_shard_rows",
            "launch_raymarch_debug", "RRTError", "device_count", "abi_version"]
@@ -171,6 +172,50 @@ class Workspace:
             pass
 
 
+class NoiseTable:
+    """Caller-owned lattice-hash tables for the volumetric noise (RenderParams.noise_table = nt.id):
+    hash31 of every lattice point the low-octave noise3D calls can reach for 0 <= time <= t_max."""
+
+    def __init__(self, t_max=32.0):
+        i = C.c_int(0)
+        _lib.check(_lib.load().rrt_noise_table_create(float(t_max), C.byref(i)), "rrt_noise_table_create")
+        self.id, self.t_max = i.value, float(t_max)
+
+    def info(self):
+        t, b, box = C.c_float(0), C.c_size_t(0), (C.c_int * 12)()
+        _lib.check(_lib.load().rrt_noise_table_info(self.id, C.byref(t), C.byref(b), C.byref(box)), "rrt_noise_table_info")
+        return {"t_max": t.value, "bytes": b.value, "accretion_box": list(box[:6]), "dust_box": list(box[6:])}
+
+    @staticmethod
+    def plan(t_max):
+        b, box = C.c_size_t(0), (C.c_int * 12)()
+        _lib.check(_lib.load().rrt_noise_table_plan(float(t_max), C.byref(b), C.byref(box)), "rrt_noise_table_plan")
+        return {"t_max": float(t_max), "bytes": b.value, "accretion_box": list(box[:6]), "dust_box": list(box[6:])}
+
+    def destroy(self):
+        if getattr(self, "id", 0):
+            _lib.load().rrt_noise_table_destroy(self.id)
+            self.id = 0
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def set_launch_defaults(params):
+    """Parameters of the reference-signature C++ entry point launch_raymarch() (None: config.h defaults)."""
+    _lib.check(_lib.load().rrt_set_launch_defaults(C.byref(params) if params is not None else None),
+               "rrt_set_launch_defaults")
+
+
+def get_launch_defaults():
+    out = RenderParams()
+    _lib.check(_lib.load().rrt_get_launch_defaults(C.byref(out)), "rrt_get_launch_defaults")
+    return out
+
+
 def _sky_handle(sky):
     return sky.handle if isinstance(sky, SkyTexture) else int(sky)
 
@@ -228,7 +273,8 @@ def assemble_all_tiles(d_frame, d_tiles_all, shard_stride_bytes, w, h, tile_rows
 
 
 def launch_raymarch_debug(d_out, w, h, time, cam, skyboxTex, effects, params=None, stream=None, **outs):
-    """Full-frame launch that also fills per-ray outputs: ldr, hdr, steps, hit, pos, vel, rad."""
+    """Full-frame launch that also fills per-ray outputs: ldr, hdr, steps, hit, pos, vel, rad (+ lut_oob, one
+    uint32 counter of out-of-box noise-table reads)."""
     dbg = rrt_debug_outputs()
     for k, v in outs.items():
         setattr(dbg, "d_" + k, _ptr(v).value if v is not None else None)

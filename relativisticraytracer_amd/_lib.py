@@ -39,13 +39,13 @@ class rrt_effects(C.Structure):
 class rrt_params(C.Structure):
     _fields_ = [("spin", C.c_float), ("max_steps", C.c_int32), ("volumetrics", C.c_int32),
                 ("sky_frac_bits", C.c_int32), ("arith_mode", C.c_int32), ("workspace", C.c_int32),
-                ("path_policy", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("path_policy", C.c_int32), ("noise_table", C.c_int32)]
 
 
 class rrt_debug_outputs(C.Structure):
     _fields_ = [("d_ldr", C.c_void_p), ("d_hdr", C.c_void_p), ("d_steps", C.c_void_p),
                 ("d_hit", C.c_void_p), ("d_pos", C.c_void_p), ("d_vel", C.c_void_p),
-                ("d_rad", C.c_void_p)]
+                ("d_rad", C.c_void_p), ("d_lut_oob", C.c_void_p)]
 
 
 # every symbol include/rrt.h declares: (name, restype, argtypes)
@@ -63,7 +63,13 @@ SYMBOLS = [
     ("rrt_sky_destroy", _i, [_ull]),
     ("rrt_workspace_create", _i, [C.c_size_t, C.POINTER(_i)]),
     ("rrt_workspace_destroy", _i, [_i]),
-    ("rrt_default_workspace", _i, [C.c_size_t, C.POINTER(_i)]),
+    ("rrt_noise_table_create", _i, [_f, C.POINTER(_i)]),
+    ("rrt_noise_table_destroy", _i, [_i]),
+    ("rrt_noise_table_info", _i, [_i, C.POINTER(_f), C.POINTER(C.c_size_t), C.POINTER(_i * 12)]),
+    ("rrt_noise_table_plan", _i, [_f, C.POINTER(C.c_size_t), C.POINTER(_i * 12)]),
+    ("rrt_set_launch_defaults", _i, [_prm]),
+    ("rrt_get_launch_defaults", _i, [_prm]),
+    ("rrt_launch_raymarch_compat", _i, [_vp, _i, _i, _f, C.POINTER(C.c_float * 12), _ull, _vp]),
     ("rrt_workspace_stats", _i, [_i, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     ("rrt_workspace_read", _i, [_i, C.c_size_t, C.c_size_t, _vp]),
     ("rrt_launch_raymarch", _i, [_vp, _i, _i, _f, _cam, _ull, _fx, _prm, _vp]),
@@ -84,6 +90,12 @@ SYMBOLS = [
     ("rrt_unit_redshift", _i, [_i, _vp, _vp, _f, _vp, _vp]),
     ("rrt_unit_math", _i, [_i, _i, _vp, _vp, _vp, _vp]),
     ("rrt_unit_sky_sample", _i, [_i, _vp, _f, _ull, _i, _vp, _vp]),
+    ("rrt_unit_disk_temperature", _i, [_i, _vp, _vp, _vp]),
+    ("rrt_unit_smoothstep", _i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    ("rrt_unit_postfx", _i, [_i, _i, _vp, _vp, _f, _vp, _vp]),
+    ("rrt_unit_rt_sample", _i, [_i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
+    ("rrt_unit_noise3d_lut", _i, [_i, _vp, _i, _i, _vp, _vp, _vp]),
+    ("rrt_unit_media_lut", _i, [_i, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     ("rrt_selfcheck_sqrt", _i, [C.c_uint32, C.c_uint32, _vp, _vp]),
     ("rrt_selfcheck_div", _i, [_ull, C.c_uint32, _vp, _vp]),
     ("rrt_camera_from_angles", _i, [C.POINTER(C.c_float * 3), _f, _f, _cam]),

@@ -16,8 +16,9 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "librrt_hip.so")
 SOURCES = [os.path.join(CSRC, "rrt_hip.hip")]
-HEADERS = [os.path.join(CSRC, "rrt_device.h"), os.path.join(CSRC, "rrt_math.h"),
-           os.path.join(PKG, "..", "include", "rrt.h")]
+COMPAT_SRC = os.path.join(CSRC, "rrt_compat.cpp")     # launch_raymarch under the reference's mangled name (host only, g++)
+HEADERS = [os.path.join(CSRC, "rrt_device.h"), os.path.join(CSRC, "rrt_math.h"), COMPAT_SRC,
+           os.path.join(PKG, "..", "include", "rrt.h"), os.path.join(PKG, "..", "include", "raymarcher.h")]
 
 # -ffp-contract=off: the kernels' arithmetic contract (csrc/rrt_device.h).
 # -fno-slp-vectorize: the SLP vectoriser packs the 3-vector math into v_pk_*_f32 plus a pile of
@@ -47,10 +48,18 @@ def build_lib(force=False, extra_flags=(), verbose=False):
     if not force and not is_stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + SOURCES + ["-o", LIB]
+    compat_obj = os.path.join(LIBDIR, "rrt_compat.o")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-c", COMPAT_SRC, "-o", compat_obj], check=True)
+    # two steps: with a .hip input hipcc compiles every input as HIP source, objects included
+    hip_obj = os.path.join(LIBDIR, "rrt_hip.o")
+    cmd = [hipcc_path()] + [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + ["-c"] + SOURCES + ["-o", hip_obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=LIBDIR)
+    link = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", hip_obj, compat_obj, "-o", LIB]
+    if verbose:
+        print(" ".join(link), flush=True)
+    subprocess.run(link, check=True, cwd=LIBDIR)
     return LIB
 
 

@@ -107,6 +107,66 @@ RRT_DEV float fbm(v3 p) {
 }
 
 /*
+ * Lattice-hash table (rrt_noise_table, include/rrt.h).
+ *
+ * noise3D spends ~108 of its ~150 VALU instructions hashing the eight corners of the lattice cell, and
+ * hash31 of a lattice point is a pure function of three integers.  For the noise calls whose cells are
+ * shared by most lanes of a wavefront (the low octaves: a wave covers 8x8 neighbouring pixels, whose
+ * sample points lie a few hundredths of a lattice cell apart) the corner values are READ instead, from a
+ * dense table over the box of lattice points those calls can reach, built once by the same hash31 code
+ * (so the bits are the same): the vector-memory pipe and the L1/L2, which the march leaves idle, take
+ * over two thirds of the call's VALU work.  Measured (tools/noise_table_microbench.hip): 2.0-2.4x per
+ * call while the wave's cells span a few cache lines, many times SLOWER when every lane has its own --
+ * hence the wave-uniform gate (lut_spread / lut_fits) in front of every table call.
+ *
+ * Record of lattice point (x, y, z), 16 bytes:
+ *   { H(x,y,z),  H(x+1,y,z) - H(x,y,z),  H(x,y+1,z),  H(x+1,y+1,z) - H(x,y+1,z) }
+ * so that lerp(H(x..), H(x+1..), t) = a + t*(b - a) of math_utils.h:41 keeps its three roundings: the
+ * stored difference is the rounded (b - a).  A cell needs the records (x,y,z) and (x,y,z+1).
+ * Layout [z][y][x]; `origin` folds the box origin into one constant; `last` clamps the index so that a
+ * read can never leave the allocation (the host proves the box covers every reachable cell for the
+ * launch's `time`, tests count violations in debug launches).
+ */
+struct NoiseLut {
+    const float4* cells;
+    int origin;            /* (z0*ny + y0)*nx + x0 */
+    int nx, nxy;
+    unsigned last;         /* n_cells - nxy - 1 */
+};
+
+RRT_DEV float noise3d_lut(const NoiseLut& L, v3 p, unsigned* oob) {
+    float ix = floorf(p.x), iy = floorf(p.y), iz = floorf(p.z);
+    float fx = p.x - ix, fy = p.y - iy, fz = p.z - iz;
+    float ux = fx * fx * (3.0f - 2.0f * fx);
+    float uy = fy * fy * (3.0f - 2.0f * fy);
+    float uz = fz * fz * (3.0f - 2.0f * fz);
+    const int cx = (int)ix, cy = (int)iy, cz = (int)iz;
+    const unsigned want = (unsigned)(__mul24(cz, L.nxy) + __mul24(cy, L.nx) + cx - L.origin);
+    const unsigned idx = want < L.last ? want : L.last;
+    if (oob && want > L.last) atomicAdd(oob, 1u);
+    const char* base = reinterpret_cast<const char*>(L.cells);
+    const float4 q0 = *reinterpret_cast<const float4*>(base + (size_t)(idx << 4));
+    const float4 q1 = *reinterpret_cast<const float4*>(base + (size_t)((idx + (unsigned)L.nxy) << 4));
+    float a = q0.x + ux * q0.y;
+    float b = q0.z + ux * q0.w;
+    float c = q1.x + ux * q1.y;
+    float d = q1.z + ux * q1.w;
+    return lerp(lerp(a, b, uy), lerp(c, d, uy), uz);
+}
+
+/* Per-lane distance (in lattice cells at scale 1, x weighted 1/4: a 128-byte line holds 8 x-neighbours) of
+ * this lane's noise-space point from the first active lane's; lut_fits(spread, s) is wave-uniform: at `s`
+ * cells per unit all active lanes stay within kLutCells cells of each other. */
+constexpr float kLutCells = 4.0f;
+RRT_DEV float lut_spread(v3 c) {
+    const float fx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.x)));
+    const float fy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.y)));
+    const float fz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.z)));
+    return __builtin_fmaxf(__builtin_fmaxf(fabsf(c.x - fx) * 0.25f, fabsf(c.y - fy)), fabsf(c.z - fz));
+}
+RRT_DEV bool lut_fits(float spread, float cells_per_unit) { return __all(spread * cells_per_unit <= kLutCells); }
+
+/*
  * Correctly rounded sqrt and divide for the march loop.
  *
  * hipcc's own expansions of sqrtf and `/` are correctly rounded too, but carry range
@@ -280,9 +340,8 @@ RRT_DEV void integrate_rk4_fast(v3& p, v3& v, float h, float hh, float h6, float
     p = axpy(kp_sum, h6, p0);
 }
 
-/* calculateRedshiftFactor, geodesics.h:11-25 */
-RRT_DEV float redshift_factor(v3 p, v3 ray_vel, float spin) {
-    float r = length(p);
+/* calculateRedshiftFactor, geodesics.h:11-25; `r` = length(p) is passed in by callers that already hold it */
+RRT_DEV float redshift_factor_r(v3 p, float r, v3 ray_vel, float spin) {
     if (r < kEventHorizon * 1.01f) return 0.0f;
     float g_gravity = sqrtf(1.0f - kEventHorizon / r);
     float v_mag = 1.0f / (rrt_powf(r, 1.5f) + spin);
@@ -292,6 +351,7 @@ RRT_DEV float redshift_factor(v3 p, v3 ray_vel, float spin) {
     float g_doppler = 1.0f / (gamma * (1.0f - v_mag * cos_theta));
     return g_gravity * g_doppler;
 }
+RRT_DEV float redshift_factor(v3 p, v3 ray_vel, float spin) { return redshift_factor_r(p, length(p), ray_vel, spin); }
 
 /* getDiskTemperature, densities.h:12-15 */
 RRT_DEV float disk_temperature(float r) {
@@ -299,107 +359,185 @@ RRT_DEV float disk_temperature(float r) {
     return kDiskTempRef * rrt_powf(r / kIsco, -0.75f);
 }
 
-/* getAccretionDensity, densities.h:20-62.  EARLY_OUT=false is the literal function
- * (unit tests); the render kernels use EARLY_OUT=true (see below). */
-template <bool EARLY_OUT>
-RRT_DEV float accretion_density(v3 p, float time) {
-    float r = sqrtf(p.x * p.x + 0.0f * 0.0f + p.z * p.z);
-    if (r < kIsco || r > kDiskOut) return 0.0f;
+/* one noise3D evaluation, from the table when the wave-uniform switch says so */
+template <bool LUT>
+RRT_DEV float noise3d_sel(v3 p, const NoiseLut& L, bool from_table, unsigned* oob) {
+    if (LUT && from_table) return noise3d_lut(L, p, oob);
+    return noise3d(p);
+}
 
-    float edge_falloff = 1.0f;
-    const float edge_start = kDiskOut * 0.85f;
-    if (r > edge_start) {
-        edge_falloff = 1.0f - (r - edge_start) / (kDiskOut - edge_start);
-        edge_falloff *= edge_falloff;
+/* fbm(p, 2) (math_utils.h:112-121) with a table switch per octave */
+template <bool LUT>
+RRT_DEV float fbm2_sel(v3 p, const NoiseLut& L, bool t0, bool t1, unsigned* oob) {
+    float v = 0.0f, a = 0.5f;
+#pragma unroll 1
+    for (int i = 0; i < 2; ++i) {
+        v += a * noise3d_sel<LUT>(p, L, i == 0 ? t0 : t1, oob);
+        p = mk(p.x * 2.05f + 10.0f, p.y * 2.05f + 10.0f, p.z * 2.05f + 10.0f);
+        a *= 0.5f;
     }
-    float q = kIsco / r;
-    float local_h = kDiskH * rrt_powf(q, 0.5f);
-    float vertical_density = rrt_expf(-(p.y * p.y) / (2.0f * local_h * local_h + 1e-7f));
-    float radial_density = rrt_powf(q, 0.4f);
-    float base_envelope = vertical_density * radial_density * edge_falloff;
+    return v;
+}
+
+/* Highest octave of each noise call family that the tables cover (rrt_hip.hip sizes the boxes from these). */
+constexpr int kLutAccOctaves = 4;      /* accretion fbm(.,5): octaves 0..3 */
+constexpr int kLutRidgeOctaves = 3;    /* dust ridge sum: octaves 0..2 */
+
+/*
+ * getAccretionDensity, densities.h:20-62.  EARLY_OUT=false, LUT=false is the literal function (unit
+ * tests); the render kernels use EARLY_OUT=true (see below) and, with a noise table, LUT=true.
+ */
+template <bool EARLY_OUT, bool LUT>
+RRT_DEV float accretion_density(v3 p, float time, const NoiseLut& L, unsigned* oob) {
+    const float rc = sqrtf(p.x * p.x + 0.0f * 0.0f + p.z * p.z);
+    if (rc < kIsco || rc > kDiskOut) return 0.0f;
+
+    float rim = 1.0f;                                   /* taper of the outer 15 % (:25-30) */
+    const float rim_from = kDiskOut * 0.85f;
+    if (rc > rim_from) {
+        rim = 1.0f - (rc - rim_from) / (kDiskOut - rim_from);
+        rim *= rim;
+    }
+    const float q = kIsco / rc;
+    const float thick = kDiskH * rrt_powf(q, 0.5f);
+    const float slab = rrt_expf(-(p.y * p.y) / (2.0f * thick * thick + 1e-7f));
+    const float fall = rrt_powf(q, 0.4f);
+    const float envelope = slab * fall * rim;
 
     /*
-     * Exact early-out (not in the reference): cloud <= 6 (densities.h:59), so the
-     * result is <= base_envelope * (0.02f + 5.0f*6.0f); rounding is monotone, so
-     * if that bound is <= 0.001f the caller's `d_disk > 0.001f` test
-     * (raymarcher.cu:71,76) fails and the value is never used.
+     * Exact early-out (not in the reference): the streak factor is <= 6 (densities.h:59), so the
+     * result is <= envelope * (0.02f + 5.0f*6.0f); rounding is monotone, so if that bound is
+     * <= 0.001f the caller's `d_disk > 0.001f` test (raymarcher.cu:71,76) fails and the value is
+     * never used.
      */
-    if (EARLY_OUT && base_envelope * (0.02f + 5.0f * 6.0f) <= 0.001f) return 0.0f;
+    if (EARLY_OUT && envelope * (0.02f + 5.0f * 6.0f) <= 0.001f) return 0.0f;
 
-    float phi = rrt_atan2f(p.z, p.x);
-    float omega = 3.5f * rrt_powf(q, 1.5f);
-    float angle_rotated = phi - time * omega;
+    const float azimuth = rrt_atan2f(p.z, p.x);
+    const float kepler = 3.5f * rrt_powf(q, 1.5f);
+    const float turned = azimuth - time * kepler;
     float sn, cs;
-    rrt_sincosf(angle_rotated, &sn, &cs);
-    v3 rot_p = mk(r * cs, p.y * 4.0f, r * sn);
-    float evolution = time * 0.35f;
-    v3 nc = mk(rot_p.x * 0.45f + 0.0f, rot_p.y * 0.45f + evolution, rot_p.z * 0.45f + 0.0f);
+    rrt_sincosf(turned, &sn, &cs);
+    const v3 swirl = mk(rc * cs, p.y * 4.0f, rc * sn);
+    const float drift = time * 0.35f;
+    v3 at = mk(swirl.x * 0.45f + 0.0f, swirl.y * 0.45f + drift, swirl.z * 0.45f + 0.0f);
 
-    float n = fbm<5>(nc);
-    float cloud = fmax2(0.0f, n - 0.32f);
-    cloud = rrt_powf(cloud * 2.8f, 1.6f);
-    cloud = fmin2(6.0f, cloud);
-    return base_envelope * (0.02f + 5.0f * cloud);
+    unsigned from_table = 0u;                           /* bit o: octave o is read from the table */
+    if (LUT) {
+        const float sp = lut_spread(at);
+        float cells = 1.0f;
+#pragma unroll
+        for (int o = 0; o < kLutAccOctaves; ++o) {
+            if (lut_fits(sp, cells)) from_table |= 1u << o;
+            cells *= 2.05f;
+        }
+    }
+    float n = 0.0f, amp = 0.5f;                         /* fbm(at, 5), math_utils.h:112-121 */
+#pragma unroll 1
+    for (int o = 0; o < 5; ++o) {
+        n += amp * noise3d_sel<LUT>(at, L, (from_table >> o) & 1u, oob);
+        at = mk(at.x * 2.05f + 10.0f, at.y * 2.05f + 10.0f, at.z * 2.05f + 10.0f);
+        amp *= 0.5f;
+    }
+    float streak = fmax2(0.0f, n - 0.32f);
+    streak = rrt_powf(streak * 2.8f, 1.6f);
+    streak = fmin2(6.0f, streak);
+    return envelope * (0.02f + 5.0f * streak);
 }
 
 /* getDustCloudDensity, densities.h:69-132 */
-RRT_DEV float dust_density(v3 p, float time) {
-    float r = sqrtf(p.x * p.x + 0.0f * 0.0f + p.z * p.z);
-    if (r < kIsco || r > kDiskOut) return 0.0f;
+template <bool LUT>
+RRT_DEV float dust_density(v3 p, float time, const NoiseLut& L, unsigned* oob) {
+    const float rc = sqrtf(p.x * p.x + 0.0f * 0.0f + p.z * p.z);
+    if (rc < kIsco || rc > kDiskOut) return 0.0f;
 
-    float edge_falloff = smoothstep(kDiskOut, kDiskOut * 0.8f, r);
-    float inner_taper = smoothstep(kIsco, kIsco + 5.0f, r);
-    float q = kIsco / r;
-    float local_h = kCloudH * 0.5f * rrt_powf(q, 0.2f);
-    float vertical_profile = rrt_expf(-(p.y * p.y) / (2.0f * local_h * local_h + 1e-7f));
-    float base = vertical_profile * edge_falloff * inner_taper;
-    if (base < 0.001f) return 0.0f;
+    const float outer = smoothstep(kDiskOut, kDiskOut * 0.8f, rc);
+    const float inner = smoothstep(kIsco, kIsco + 5.0f, rc);
+    const float q = kIsco / rc;
+    const float thick = kCloudH * 0.5f * rrt_powf(q, 0.2f);
+    const float slab = rrt_expf(-(p.y * p.y) / (2.0f * thick * thick + 1e-7f));
+    const float envelope = slab * outer * inner;
+    if (envelope < 0.001f) return 0.0f;                 /* densities.h:85 */
 
-    float phi = rrt_atan2f(p.z, p.x);
-    float omega = rrt_powf(q, 1.5f);                   /* 1.0f * pow(...) */
-    float angle_rot = phi - time * omega;
+    const float azimuth = rrt_atan2f(p.z, p.x);
+    const float kepler = rrt_powf(q, 1.5f);             /* 1.0f * pow(...) */
+    const float sheared = azimuth - time * kepler;
 
-    v3 coords = mk(r * 0.8f, p.y * 15.0f, angle_rot * 10.0f);
-    v3 c15 = mul(coords, 0.15f);
-    v3 w1 = mk(fbm<2>(c15),
-               fbm<2>(mk(c15.x + 1.0f, c15.y + 2.0f, c15.z + 3.0f)),
-               fbm<2>(mk(c15.x + 4.0f, c15.y + 5.0f, c15.z + 6.0f)));
-    v3 w2c = add(coords, mul(w1, 3.0f));
-    v3 c40 = mul(w2c, 0.4f);
-    v3 w2 = mk(fbm<2>(c40),
-               fbm<2>(mk(c40.x + 2.0f, c40.y + 1.0f, c40.z + 0.0f)),
-               fbm<2>(mk(c40.x + 0.0f, c40.y + 3.0f, c40.z + 1.0f)));
-    v3 fc = add(coords, mul(w2, 1.5f));
+    const v3 sc = mk(rc * 0.8f, p.y * 15.0f, sheared * 10.0f);     /* `coords`, :93 */
 
-    float n = 0.0f, amp = 1.0f, freq = 1.0f;
+    /* table switches, wave-uniform: bit 0/1 warp-1 octaves, 2/3 warp-2 octaves, 4.. ridge octaves,
+     * 8 detail octave 0; the scales are the factors each family applies to `sc` */
+    unsigned from_table = 0u;
+    if (LUT) {
+        const float sp = lut_spread(sc);
+        if (lut_fits(sp, 0.15f)) from_table |= 1u;
+        if (lut_fits(sp, 0.15f * 2.05f)) from_table |= 2u;
+        if (lut_fits(sp, 0.4f)) from_table |= 4u;
+        if (lut_fits(sp, 0.4f * 2.05f)) from_table |= 8u;
+        float cells = 1.0f;
+#pragma unroll
+        for (int k = 0; k < kLutRidgeOctaves; ++k) {
+            if (lut_fits(sp, cells)) from_table |= 16u << k;
+            cells *= 2.1f;
+        }
+        if (lut_fits(sp, 4.0f)) from_table |= 256u;             /* the detail fbm's second octave (8.2 cells per unit) is never coherent */
+    }
+
+    /* first warp, :95-99: fbm(c, 2), fbm(c + (1,2,3), 2), fbm(c + (4,5,6), 2) with c = sc*0.15
+     * (c + 0 for the first: adding +0.0f changes no result, see noise3d) */
+    const v3 c15 = mul(sc, 0.15f);
+    float wx = 0.f, wy = 0.f, wz = 0.f;
 #pragma unroll 1
-    for (int i = 0; i < 5; ++i) {
-        float nv = noise3d(mul(fc, freq));
-        float wisp = 1.0f - fabsf(nv * 2.0f - 1.0f);
+    for (int k = 0; k < 3; ++k) {
+        const float ox = k == 0 ? 0.0f : (k == 1 ? 1.0f : 4.0f);
+        const float oy = k == 0 ? 0.0f : (k == 1 ? 2.0f : 5.0f);
+        const float oz = k == 0 ? 0.0f : (k == 1 ? 3.0f : 6.0f);
+        const float f = fbm2_sel<LUT>(mk(c15.x + ox, c15.y + oy, c15.z + oz), L, from_table & 1u, from_table & 2u, oob);
+        if (k == 0) wx = f; else if (k == 1) wy = f; else wz = f;
+    }
+    /* second warp, :101-106: offsets (0,0,0), (2,1,0), (0,3,1) on (sc + 3*w1)*0.4 */
+    const v3 c40 = mul(add(sc, mul(mk(wx, wy, wz), 3.0f)), 0.4f);
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < 3; ++k) {
+        const float ox = k == 1 ? 2.0f : 0.0f;
+        const float oy = k == 0 ? 0.0f : (k == 1 ? 1.0f : 3.0f);
+        const float oz = k == 2 ? 1.0f : 0.0f;
+        const float f = fbm2_sel<LUT>(mk(c40.x + ox, c40.y + oy, c40.z + oz), L, from_table & 4u, from_table & 8u, oob);
+        if (k == 0) vx = f; else if (k == 1) vy = f; else vz = f;
+    }
+    const v3 fc = add(sc, mul(mk(vx, vy, vz), 1.5f));              /* `final_coords`, :108 */
+
+    float n = 0.0f, amp = 1.0f, freq = 1.0f;                       /* ridged sum, :111-120 */
+#pragma unroll 1
+    for (int k = 0; k < 5; ++k) {
+        const float nv = noise3d_sel<LUT>(mul(fc, freq), L, (from_table >> (4 + k)) & 1u & (k < kLutRidgeOctaves ? 1u : 0u), oob);
+        const float wisp = 1.0f - fabsf(nv * 2.0f - 1.0f);
         n += wisp * amp;
         amp *= 0.5f;
         freq *= 2.1f;
     }
     float strands = smoothstep(0.4f, 0.8f, n * 0.55f);
     strands = rrt_powf(strands, 4.0f);
-    v3 dc = mul(fc, 4.0f);
-    float detail = fbm<2>(mk(dc.x + 0.0f, dc.y + time * 0.5f, dc.z + 0.0f));
+    const v3 dc = mul(fc, 4.0f);
+    const float detail = fbm2_sel<LUT>(mk(dc.x + 0.0f, dc.y + time * 0.5f, dc.z + 0.0f), L, from_table & 256u, false, oob);
     strands *= (0.6f + 0.4f * detail);
-    return base * strands * 12.0f;
+    return envelope * strands * 12.0f;
 }
 
 /* ---- radiative transfer of one in-zone sample, raymarcher.cu:67-117 ---- */
 struct Radiance { float r, g, b, t; };
 
 /* Emission (ex, ey, ez) and transmittance of one sample; false when the sample contributes nothing
- * (raymarcher.cu:71 not taken). */
+ * (raymarcher.cu:71 not taken).  The reference evaluates calculateRedshiftFactor(rel_p, vel) in both
+ * components (:77, :92) with the same arguments; it is evaluated once here. */
 RRT_DEV bool sample_emission(float d_disk, float d_cloud, v3 rel_p, float r, v3 vel, float h, float spin,
                              float& ex, float& ey, float& ez, float& step_trans) {
-    if (!(d_disk > 0.001f || d_cloud > 0.001f)) return false;
+    const bool disk_on = d_disk > 0.001f, dust_on = d_cloud > 0.001f;
+    if (!(disk_on || dust_on)) return false;
     ex = 0.f; ey = 0.f; ez = 0.f;
     float opacity = 0.f;
-    if (d_disk > 0.001f) {
-        float g = redshift_factor(rel_p, vel, spin);
+    const float g = redshift_factor_r(rel_p, r, vel, spin);
+    if (disk_on) {
         float T = disk_temperature(r);
         float tn = T / kDiskTempRef;
         float T_norm = rrt_powf(tn, 0.5f);
@@ -410,8 +548,7 @@ RRT_DEV bool sample_emission(float d_disk, float d_cloud, v3 rel_p, float r, v3 
         ez += fmax2(0.0f, 0.01f * (color_t - 2.0f)) * bol_I;
         opacity += d_disk * kDiskOpacity;
     }
-    if (d_cloud > 0.001f) {
-        float g = redshift_factor(rel_p, vel, spin);
+    if (dust_on) {
         float lighting = 0.5f + 3.0f * rrt_powf(kIsco / fmax2(r, kIsco), 1.2f);
         float cloud_I = d_cloud * kCloudLum * lighting;
         float shift = smoothstep(0.7f, 1.3f, g);
@@ -439,6 +576,26 @@ RRT_DEV void accumulate_sample(Radiance& acc, float d_disk, float d_cloud, v3 re
     float ex, ey, ez, s;
     if (!sample_emission(d_disk, d_cloud, rel_p, r, vel, h, spin, ex, ey, ez, s)) return;
     accumulate_emission(acc, ex, ey, ez, s);
+}
+
+/* ---- per-pixel camera effects, camera_effects/post_processing.h:13-31 ---- */
+RRT_DEV void lens_distort(float& uvx, float& uvy, float k) {                 /* apply_lens_distortion :19-24 */
+    const float tx = uvx - 0.5f, ty = uvy - 0.5f;
+    const float r2 = tx * tx + ty * ty;
+    const float f = 1.0f + r2 * k;
+    uvx = tx * f + 0.5f;
+    uvy = ty * f + 0.5f;
+}
+RRT_DEV v3 bloom_part(v3 c, float threshold) {                               /* get_bloom_contribution :27-31 */
+    const float luma = c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f;
+    const bool on = luma > threshold;
+    return mk(on ? c.x : 0.f, on ? c.y : 0.f, on ? c.z : 0.f);
+}
+RRT_DEV v3 vignette(v3 c, float uvx, float uvy, float intensity) {           /* apply_vignette :13-17 */
+    const float dx = uvx - 0.5f, dy = uvy - 0.5f;
+    const float dist = sqrtf(dx * dx + dy * dy + 0.0f * 0.0f);
+    const float vg = smoothstep(0.8f, 0.2f, dist * intensity);
+    return mul(c, vg);
 }
 
 /* ---- sky lookup (replaces tex2D<float4>, raymarcher.cu:134-146; the filter is the

@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
     rrt_params prm; rrt_params_default(&prm);
     prm.spin = spin; prm.arith_mode = fast ? RRT_ARITH_FAST : RRT_ARITH_STRICT;
     int ws = 0;
-    if (rrt_default_workspace((size_t)2 << 30, &ws) == RRT_OK) prm.workspace = ws;
+    if (rrt_workspace_create((size_t)2 << 30, &ws) == RRT_OK) prm.workspace = ws;
 
     void* d_out = nullptr;
     const size_t bytes = (size_t)w * h * 4;

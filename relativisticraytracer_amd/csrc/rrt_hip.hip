@@ -85,6 +85,7 @@ rrt_sky_t sky_register(const SkyObject& s) {
 struct DeferCounters { unsigned next_block, overflow_waves, pad0, pad1; };
 struct WaveHdr { unsigned first_block, n_runs, state, pad; };     /* state: 1 marched, 2 marched until the pool ran out */
 constexpr unsigned kMaxRun = 32;
+constexpr unsigned kMaxRunsWalked = 4096;                          /* runs of one wave that pass 3 will walk */
 constexpr unsigned kBlockRows = 8;
 constexpr unsigned kRowData = 6 * 256;
 constexpr unsigned kBlockTrailer = kBlockRows * kRowData;         /* masks[kBlockRows] (u64), then next (u32) */
@@ -95,6 +96,118 @@ struct WorkspaceObject { uint8_t* d_base; size_t bytes; };
 std::mutex g_ws_mu;
 std::unordered_map<int, WorkspaceObject> g_ws;
 int g_ws_next = 1;
+
+/* ------------------------------------------------------------------ lattice-hash tables (rrt_noise_table)
+ * Two dense boxes of the integer lattice, one for the accretion fbm and one for the dust-cloud noise calls
+ * (layout and use: NoiseLut in rrt_device.h).  The boxes are computed on the host from the coordinate ranges
+ * those calls can reach for 0 <= time <= t_max (lut_boxes below); a launch with a time outside that range
+ * simply runs the arithmetic kernels. */
+struct LutBox { int x0, y0, z0, nx, ny, nz; };
+struct NoiseTableObject {
+    float4* d_cells;          /* accretion box, then dust box */
+    size_t bytes;
+    float t_max;
+    LutBox acc, dust;
+    int device;
+};
+std::mutex g_nt_mu;
+std::unordered_map<int, NoiseTableObject> g_nt;
+int g_nt_next = 1;
+
+struct Interval {
+    double lo, hi;
+    Interval scaled(double s) const { return s >= 0 ? Interval{lo * s, hi * s} : Interval{hi * s, lo * s}; }
+    Interval shifted(double a, double b) const { return Interval{lo + a, hi + b}; }      /* + [a, b] */
+    Interval widened(double w) const { return Interval{lo - w, hi + w}; }
+};
+struct Reach {                 /* running union of the lattice points a noise3D call family can touch */
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    void add(const Interval c[3]) {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], c[k].lo); hi[k] = std::fmax(hi[k], c[k].hi); }
+    }
+    /* `octaves` octaves of fbm starting at c: p -> p*2.05 + 10 (math_utils.h:116) */
+    void add_fbm(Interval c[3], int octaves) {
+        for (int o = 0; o < octaves; ++o) {
+            add(c);
+            for (int k = 0; k < 3; ++k) c[k] = c[k].scaled(2.05).shifted(10.0, 10.0);
+        }
+    }
+    LutBox box() const {       /* floor(lo) .. floor(hi) + 1 are the corners used; two cells of slack on every side */
+        LutBox b;
+        int l[3], h[3];
+        for (int k = 0; k < 3; ++k) { l[k] = (int)std::floor(lo[k]) - 2; h[k] = (int)std::floor(hi[k]) + 1 + 2; }
+        b.x0 = l[0]; b.y0 = l[1]; b.z0 = l[2];
+        b.nx = h[0] - l[0] + 1; b.ny = h[1] - l[1] + 1; b.nz = h[2] - l[2] + 1;
+        return b;
+    }
+};
+
+/* Coordinate ranges of the table-served noise calls for 0 <= time <= t_max, from the constants of
+ * densities.h (every bound is taken generously: the functions only run for rc in [10, 25], the
+ * accretion one for |y| < 4 and the dust one for |y| < 0.75 -- the zone tests of raymarcher.cu:57-58 --
+ * |sin|, |cos| <= 1 + 1e-6, |atan2| <= pi + 1e-6, |noise3D| < 1 + 1e-6, hence |fbm(.,2)| < 0.76). */
+void lut_boxes(double t_max, LutBox& acc, LutBox& dust) {
+    const double pi = 3.14159265358979 + 1e-5;
+    {   /* getAccretionDensity, densities.h:44-54: (rc cos, 4y, rc sin)*0.45 + (0, 0.35 t, 0) */
+        Reach r;
+        Interval c[3] = {Interval{-25.0, 25.0}.scaled(0.45).widened(1e-3),
+                         Interval{-16.0, 16.0}.scaled(0.45).shifted(0.0, 0.35 * t_max).widened(1e-3),
+                         Interval{-25.0, 25.0}.scaled(0.45).widened(1e-3)};
+        r.add_fbm(c, rrt::kLutAccOctaves);
+        acc = r.box();
+    }
+    {   /* getDustCloudDensity, densities.h:93: coords = (0.8 rc, 15 y, 10 (phi - t*omega)), omega in (0, 1] */
+        Reach r;
+        const Interval sc[3] = {Interval{8.0, 20.0}.widened(1e-3), Interval{-11.25, 11.25}.widened(1e-3),
+                                Interval{-(pi + t_max) * 10.0, pi * 10.0}.widened(1e-2)};
+        const double off1[3][3] = {{0, 0, 0}, {1, 2, 3}, {4, 5, 6}}, off2[3][3] = {{0, 0, 0}, {2, 1, 0}, {0, 3, 1}};
+        for (int k = 0; k < 3; ++k) {                          /* :95-99 */
+            Interval c[3];
+            for (int ax = 0; ax < 3; ++ax) c[ax] = sc[ax].scaled(0.15).shifted(off1[k][ax], off1[k][ax]);
+            r.add_fbm(c, 2);
+        }
+        for (int k = 0; k < 3; ++k) {                          /* :101-106: (coords + 3 w1)*0.4 + offsets */
+            Interval c[3];
+            for (int ax = 0; ax < 3; ++ax) c[ax] = sc[ax].widened(3.0 * 0.76).scaled(0.4).shifted(off2[k][ax], off2[k][ax]);
+            r.add_fbm(c, 2);
+        }
+        double freq = 1.0;
+        for (int k = 0; k < rrt::kLutRidgeOctaves; ++k) {      /* :111-120: (coords + 1.5 w2)*freq */
+            Interval c[3];
+            for (int ax = 0; ax < 3; ++ax) c[ax] = sc[ax].widened(1.5 * 0.76).scaled(freq);
+            r.add(c);
+            freq *= 2.1;
+        }
+        {                                                      /* :127: (coords + 1.5 w2)*4 + (0, 0.5 t, 0), first octave only */
+            Interval c[3];
+            for (int ax = 0; ax < 3; ++ax) c[ax] = sc[ax].widened(1.5 * 0.76).scaled(4.0);
+            c[1] = c[1].shifted(0.0, 0.5 * t_max);
+            r.add_fbm(c, 1);
+        }
+        dust = r.box();
+    }
+}
+
+__global__ __launch_bounds__(256) void build_noise_table(float4* cells, LutBox b) {
+    const size_t n = (size_t)b.nx * b.ny * b.nz;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % b.nx), y = (int)((i / b.nx) % b.ny), z = (int)(i / ((size_t)b.nx * b.ny));
+        /* "+ 0.0f": the lattice coordinate as noise3d() forms it (ix + 0.0f, ix + 1.0f; rrt_device.h) */
+        const float fx = (float)(x + b.x0) + 0.0f, fy = (float)(y + b.y0) + 0.0f, fz = (float)(z + b.z0) + 0.0f;
+        const float h00 = hash31(fx, fy, fz), h10 = hash31(fx + 1.0f, fy, fz);
+        const float h01 = hash31(fx, fy + 1.0f, fz), h11 = hash31(fx + 1.0f, fy + 1.0f, fz);
+        cells[i] = make_float4(h00, h10 - h00, h01, h11 - h01);
+    }
+}
+
+NoiseLut make_lut(const float4* cells, const LutBox& b) {
+    NoiseLut L;
+    L.cells = cells;
+    L.nx = b.nx; L.nxy = b.nx * b.ny;
+    L.origin = (b.z0 * b.ny + b.y0) * b.nx + b.x0;
+    L.last = (unsigned)((size_t)b.nx * b.ny * b.nz - (size_t)L.nxy - 1);
+    return L;
+}
 
 /* ------------------------------------------------------------------ kernel arguments */
 struct RowMap {        /* local row -> image row, and where its pixels go */
@@ -126,6 +239,8 @@ struct FrameArgs {
     size_t n_lanes;
     uint8_t* sample_blocks;
     unsigned block_capacity;
+    /* lattice-hash tables (rrt_noise_table); only read by the kernels instantiated with MEDIA == 2 */
+    NoiseLut lut_acc, lut_dust;
 };
 
 /* image row of local row `lr`, and the local output row it is stored at */
@@ -146,13 +261,7 @@ __device__ __forceinline__ bool map_row(const RowMap& m, int height, int lr, int
 __device__ __forceinline__ void primary_ray(const FrameArgs& a, int x, int y, float& uvx, float& uvy, v3& p, v3& vel) {
     uvx = (float)x / (float)a.width;
     uvy = (float)y / (float)a.height;
-    if (a.use_lens) {
-        float tx = uvx - 0.5f, ty = uvy - 0.5f;
-        float r2 = tx * tx + ty * ty;
-        float f = 1.0f + r2 * a.distortion_amount;
-        uvx = tx * f + 0.5f;
-        uvy = ty * f + 0.5f;
-    }
+    if (a.use_lens) lens_distort(uvx, uvy, a.distortion_amount);
     float u_coord = uvx * 2.0f - 1.0f;
     float v_coord = uvy * 2.0f - 1.0f;
     float aspect = (float)a.width / (float)a.height;
@@ -187,18 +296,14 @@ __device__ __forceinline__ void shade_and_store(const FrameArgs& a, int x, int y
 
     /* raymarcher.cu:154-161, post_processing.h:13-31 */
     if (a.use_bloom) {
-        float brightness = hx * 0.2126f + hy * 0.7152f + hz * 0.0722f;
-        bool on = brightness > a.bloom_threshold;
-        float bx = on ? hx : 0.f, by = on ? hy : 0.f, bz = on ? hz : 0.f;
-        hx = hx + bx * a.bloom_intensity;
-        hy = hy + by * a.bloom_intensity;
-        hz = hz + bz * a.bloom_intensity;
+        const v3 bl = bloom_part(mk(hx, hy, hz), a.bloom_threshold);
+        hx = hx + bl.x * a.bloom_intensity;
+        hy = hy + bl.y * a.bloom_intensity;
+        hz = hz + bl.z * a.bloom_intensity;
     }
     if (a.use_vignette) {
-        float dx = uvx - 0.5f, dy = uvy - 0.5f;
-        float dd = sqrtf(dx * dx + dy * dy + 0.0f * 0.0f);
-        float vg = smoothstep(0.8f, 0.2f, dd * a.vignette_intensity);
-        hx *= vg; hy *= vg; hz *= vg;
+        const v3 vg = vignette(mk(hx, hy, hz), uvx, uvy, a.vignette_intensity);
+        hx = vg.x; hy = vg.y; hz = vg.z;
     }
 
     /* raymarcher.cu:164-173 */
@@ -246,9 +351,11 @@ __device__ __forceinline__ void march_radius(v3 rel_p, float& r2, float& r, floa
     }
 }
 
-/* The whole march of one ray with the media sampled in line: raymarcher.cu:41-121. */
-template <bool SPIN, bool VOL, bool FAST>
-__device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel, Radiance& acc, bool& hit, int& i) {
+/* The whole march of one ray with the media sampled in line: raymarcher.cu:41-121.
+ * MEDIA: 0 = densities read 0 ("skybox only"), 1 = full media, 2 = full media with the lattice-hash tables. */
+template <bool SPIN, int MEDIA, bool FAST>
+__device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel, Radiance& acc, bool& hit, int& i,
+                                             unsigned* oob) {
     for (; i < a.max_steps; ++i) {
         const v3 rel_p = p;                             /* p - MASS_POS, MASS_POS = 0 */
         float r2, r, y;
@@ -265,9 +372,9 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
         if (FAST) integrate_rk4_fast<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, y);
         else integrate_rk4_r<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, r, y);
 
-        if (VOL && (in_disk || in_cloud)) {
-            float d_disk = in_disk ? accretion_density<true>(rel_p, a.time) : 0.0f;
-            float d_cloud = in_cloud ? dust_density(rel_p, a.time) : 0.0f;
+        if (MEDIA != 0 && (in_disk || in_cloud)) {
+            float d_disk = in_disk ? accretion_density<true, MEDIA == 2>(rel_p, a.time, a.lut_acc, oob) : 0.0f;
+            float d_cloud = in_cloud ? dust_density<MEDIA == 2>(rel_p, a.time, a.lut_dust, oob) : 0.0f;
             accumulate_sample(acc, d_disk, d_cloud, rel_p, r, vel, h, a.spin);
         }
         if (r > 250.0f && dot(rel_p, vel) > 0.0f) { ++i; break; }
@@ -313,7 +420,7 @@ __device__ __forceinline__ unsigned wave_index() {
 
 /* Single-kernel path: one ray per lane, media sampled in line (reference raymarch_kernel,
  * src/raymarcher.cu:15-174). */
-template <bool SPIN, bool VOL, bool DEBUG, bool FAST>
+template <bool SPIN, int MEDIA, bool DEBUG, bool FAST>
 __global__ __launch_bounds__(kWGThreads) void raymarch_pixels(const FrameArgs a) {
     int x, y, out_row;
     if (!lane_pixel(a, x, y, out_row)) return;
@@ -323,7 +430,7 @@ __global__ __launch_bounds__(kWGThreads) void raymarch_pixels(const FrameArgs a)
     Radiance acc = {0.f, 0.f, 0.f, 1.0f};
     bool hit = false;
     int i = 0;
-    march_inline<SPIN, VOL, FAST>(a, p, vel, acc, hit, i);
+    march_inline<SPIN, MEDIA, FAST>(a, p, vel, acc, hit, i, DEBUG ? a.dbg.d_lut_oob : nullptr);
     shade_and_store<DEBUG>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, i);
 }
 
@@ -389,7 +496,19 @@ __global__ __launch_bounds__(kWGThreads) __attribute__((amdgpu_num_sgpr(80))) vo
                     unsigned start = 0;
                     if (lane == leader) start = atomicAdd(&a.ctr->next_block, len);
                     start = __builtin_amdgcn_readfirstlane(start);
-                    if (start + len > a.block_capacity) { overflow = true; break; }
+                    if (start + len > a.block_capacity) {
+                        /* the pool is full: blocks [start, capacity) now belong to this failed run; give them empty
+                         * masks so that pass 2 finds nothing in them */
+                        if (lane == leader) {
+                            for (unsigned b2 = start; b2 < a.block_capacity; ++b2) {
+                                ulonglong2* m = reinterpret_cast<ulonglong2*>(a.sample_blocks + (size_t)b2 * kBlockBytes + kBlockTrailer);
+#pragma unroll
+                                for (unsigned k = 0; k < kBlockRows / 2; ++k) m[k] = make_ulonglong2(0ull, 0ull);
+                            }
+                        }
+                        overflow = true;
+                        break;
+                    }
                     if (lane == leader) {                          /* lanes 0-7 may have left the loop already */
                         for (unsigned b2 = 0; b2 < len; ++b2) {
                             ulonglong2* m = reinterpret_cast<ulonglong2*>(a.sample_blocks + (size_t)(start + b2) * kBlockBytes +
@@ -453,7 +572,7 @@ __global__ __launch_bounds__(kWGThreads) __attribute__((amdgpu_num_sgpr(80))) vo
 }
 
 /* ---- pass 2: densities + emission of every pooled sample row, grid-stride over the pool ---- */
-template <bool FAST>
+template <bool FAST, bool LUT>
 __global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
     const int lane = threadIdx.x & 63;
     const unsigned n_blk = min(a.ctr->next_block, a.block_capacity);
@@ -473,8 +592,8 @@ __global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
         const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
         const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
         const float h = near_bh ? kHNear : (in_disk ? kHDisk : kHVac);
-        const float d_disk = in_disk ? accretion_density<true>(rel_p, a.time) : 0.0f;
-        const float d_cloud = in_cloud ? dust_density(rel_p, a.time) : 0.0f;
+        const float d_disk = in_disk ? accretion_density<true, LUT>(rel_p, a.time, a.lut_acc, nullptr) : 0.0f;
+        const float d_cloud = in_cloud ? dust_density<LUT>(rel_p, a.time, a.lut_dust, nullptr) : 0.0f;
         float ex, ey, ez, s;
         if (!sample_emission(d_disk, d_cloud, rel_p, r, vel, h, a.spin, ex, ey, ez, s)) {
             ex = 0.f; ey = 0.f; ez = 0.f; s = 1.0f;       /* identity for accumulate_emission */
@@ -484,7 +603,7 @@ __global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
 }
 
 /* ---- pass 3: composite each ray's samples in march order, resume rays the pool ran out under, shade ---- */
-template <bool SPIN, bool FAST>
+template <bool SPIN, bool FAST, bool LUT>
 __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArgs a) {
     int x, y, out_row;
     if (!lane_pixel(a, x, y, out_row)) return;
@@ -500,7 +619,7 @@ __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArg
     bool hit = (code >> 31) != 0;
     Radiance acc = {0.f, 0.f, 0.f, 1.0f};
     unsigned run_start = a.hdr[wid].first_block, run_len = 1;
-    const unsigned n_runs = min(a.hdr[wid].n_runs, 4096u);
+    const unsigned n_runs = min(a.hdr[wid].n_runs, kMaxRunsWalked);
     for (unsigned rn = 0; rn < n_runs; ++rn) {
         const unsigned* link = reinterpret_cast<const unsigned*>(a.sample_blocks + (size_t)run_start * kBlockBytes +
                                                                  kBlockTrailer + kBlockRows * 8);
@@ -542,7 +661,7 @@ __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArg
         /* the pool ran out under this ray at step `steps`: carry on from its saved pre-step state with the
          * media sampled in line -- the samples composited above come first, exactly as in the single kernel */
         p = mk(a.finals[4 * a.n_lanes + li], a.finals[5 * a.n_lanes + li], a.finals[6 * a.n_lanes + li]);
-        march_inline<SPIN, true, FAST>(a, p, vel, acc, hit, steps);
+        march_inline<SPIN, LUT ? 2 : 1, FAST>(a, p, vel, acc, hit, steps, nullptr);
     }
     if (hit) acc.t = 0.0f;                                         /* raymarcher.cu:49 */
     shade_and_store<false>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, steps);
@@ -612,11 +731,11 @@ __global__ void k_fbm(int n, const float* p, int oct, float* out) {
 }
 __global__ void k_accretion(int n, const float* p, float time, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = accretion_density<false>(ld3(p, i), time);
+    if (i < n) out[i] = accretion_density<false, false>(ld3(p, i), time, NoiseLut{}, nullptr);
 }
 __global__ void k_dust(int n, const float* p, float time, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = dust_density(ld3(p, i), time);
+    if (i < n) out[i] = dust_density<false>(ld3(p, i), time, NoiseLut{}, nullptr);
 }
 __global__ void k_redshift(int n, const float* p, const float* vel, float spin, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -643,6 +762,59 @@ __global__ void k_sky(int n, const float* dir, float off, SkyTex sky, float* out
     float s[4];
     sample_sky(sky, ld3(dir, i), off, s);
     out[4 * i] = s[0]; out[4 * i + 1] = s[1]; out[4 * i + 2] = s[2]; out[4 * i + 3] = s[3];
+}
+
+__global__ void k_disk_temperature(int n, const float* r, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = disk_temperature(r[i]);
+}
+__global__ void k_smoothstep(int n, const float* e0, const float* e1, const float* x, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = smoothstep(e0[i], e1[i], x[i]);
+}
+/* what: 0 lens (uv -> uv), 1 vignette (rgb, uv -> rgb), 2 bloom contribution (rgb -> rgb) */
+__global__ void k_postfx(int what, int n, const float* rgb, const float* uv, float param, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (what == 0) {
+        float ux = uv[2 * i], uy = uv[2 * i + 1];
+        lens_distort(ux, uy, param);
+        out[2 * i] = ux; out[2 * i + 1] = uy;
+    } else if (what == 1) {
+        st3(out, i, vignette(ld3(rgb, i), uv[2 * i], uv[2 * i + 1], param));
+    } else {
+        st3(out, i, bloom_part(ld3(rgb, i), param));
+    }
+}
+/* the radiative-transfer block raymarcher.cu:71-116 on one sample per element; rad = (I_r, I_g, I_b, T) in/out.
+ * r = length(p) exactly as the march holds it. */
+__global__ void k_rt_sample(int n, const float* d_disk, const float* d_cloud, const float* p, const float* vel,
+                            const float* h, float spin, float* rad) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const v3 rp = ld3(p, i);
+    float r2, r, y;
+    march_radius<false>(rp, r2, r, y);
+    Radiance acc = {rad[4 * i], rad[4 * i + 1], rad[4 * i + 2], rad[4 * i + 3]};
+    accumulate_sample(acc, d_disk[i], d_cloud[i], rp, r, ld3(vel, i), h[i], spin);
+    rad[4 * i] = acc.r; rad[4 * i + 1] = acc.g; rad[4 * i + 2] = acc.b; rad[4 * i + 3] = acc.t;
+}
+/* noise3D through the lattice-hash table (which: 0 accretion box, 1 dust box); counts[0] += reads the clamp had to move */
+__global__ void k_noise3d_lut(int n, const float* p, NoiseLut L, float* out, unsigned* counts) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = noise3d_lut(L, ld3(p, i), counts);
+}
+/* the two density functions exactly as the render kernels call them (early-out, table switches) */
+__global__ void k_media_lut(int n, const float* p, float time, NoiseLut la, NoiseLut ld, float* out_disk, float* out_dust,
+                            unsigned* counts) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const v3 q = ld3(p, i);
+    const float r = length(q);                           /* the zone tests of raymarcher.cu:57-58 gate the calls */
+    const bool in_disk = fabsf(q.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
+    const bool in_cloud = fabsf(q.y) < kCloudH * 1.5f && r < kCloudOut;
+    out_disk[i] = in_disk ? accretion_density<true, true>(q, time, la, counts) : 0.0f;
+    out_dust[i] = in_cloud ? dust_density<true>(q, time, ld, counts) : 0.0f;
 }
 
 /*
@@ -702,12 +874,12 @@ int check_common(const void* out, int width, int height, const rrt_camera* cam, 
         if (prm->arith_mode != RRT_ARITH_STRICT && prm->arith_mode != RRT_ARITH_FAST) return RRT_ERR_INVALID_ARGUMENT;
         if (prm->workspace < 0) return RRT_ERR_INVALID_ARGUMENT;
         if (prm->path_policy < RRT_PATH_AUTO || prm->path_policy > RRT_PATH_THREE_PASS) return RRT_ERR_INVALID_ARGUMENT;
-        if (prm->reserved[0] != 0) return RRT_ERR_INVALID_ARGUMENT;
+        if (prm->noise_table < 0) return RRT_ERR_INVALID_ARGUMENT;
     }
     return RRT_OK;
 }
 
-int fill_args(FrameArgs& a, bool& vol, bool& fast, int& workspace, int& policy, void* out, int width, int height, float time, const rrt_camera* cam,
+int fill_args(FrameArgs& a, int& media, bool& fast, int& workspace, int& policy, void* out, int width, int height, float time, const rrt_camera* cam,
               rrt_sky_t sky, const rrt_effects* fx, const rrt_params* prm_in) {
     rrt_params prm;
     if (prm_in) prm = *prm_in; else rrt_params_default(&prm);
@@ -726,7 +898,23 @@ int fill_args(FrameArgs& a, bool& vol, bool& fast, int& workspace, int& policy, 
     a.drag_c = (2.0f * prm.spin) * 2.0f;            /* 2.0f * SPIN_A * EVENT_HORIZON, geodesics.h:41 */
     a.max_steps = prm.max_steps;
     memset(&a.dbg, 0, sizeof(a.dbg));
-    vol = prm.volumetrics != 0;
+    media = prm.volumetrics != 0 ? 1 : 0;
+    memset(&a.lut_acc, 0, sizeof(a.lut_acc)); memset(&a.lut_dust, 0, sizeof(a.lut_dust));
+    if (prm.noise_table != 0) {
+        NoiseTableObject nt;
+        {
+            std::lock_guard<std::mutex> lk(g_nt_mu);
+            auto it = g_nt.find(prm.noise_table);
+            if (it == g_nt.end()) return RRT_ERR_BAD_HANDLE;
+            nt = it->second;
+        }
+        /* the boxes were sized for 0 <= time <= t_max; any other time runs the arithmetic kernels */
+        if (media && time >= 0.0f && time <= nt.t_max) {
+            media = 2;
+            a.lut_acc = make_lut(nt.d_cells, nt.acc);
+            a.lut_dust = make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust);
+        }
+    }
     fast = prm.arith_mode == RRT_ARITH_FAST;
     workspace = prm.workspace;
     policy = prm.path_policy;
@@ -734,9 +922,16 @@ int fill_args(FrameArgs& a, bool& vol, bool& fast, int& workspace, int& policy, 
     return RRT_OK;
 }
 
+/* Largest max_steps the three-pass bookkeeping can represent: the step count shares a word with the hit /
+ * resume flags (30 bits), and pass 3 walks at most kMaxRunsWalked runs of a wave, whose lengths double up to
+ * kMaxRun blocks of kBlockRows rows -- a wave can pool one row per step, so it must not need more runs than
+ * that.  Launches with more steps take the single kernel (same bytes). */
+constexpr long long kThreePassMaxSteps = (long long)(kMaxRunsWalked - 8) * kMaxRun * kBlockRows;   /* ~1.05 M */
+static_assert(kThreePassMaxSteps < (1ll << 30), "step count must fit beside the two flag bits");
+
 /* Three-pass launch through a workspace.  Returns RRT_OK after enqueuing, or -1 if the workspace cannot
  * hold this launch's bookkeeping plus a useful pool (the caller then uses the single-kernel path). */
-int launch_deferred(FrameArgs a, bool fast, const WorkspaceObject& ws, hipStream_t st) {
+int launch_deferred(FrameArgs a, bool fast, bool lut, const WorkspaceObject& ws, hipStream_t st) {
     dim3 block(kWGThreads);
     dim3 grid((a.width + kWGPixX - 1) / kWGPixX, (a.rows.n_local_rows + kWGPixY - 1) / kWGPixY);
     const size_t n_waves = (size_t)grid.x * grid.y * kWGWaves;
@@ -761,13 +956,16 @@ int launch_deferred(FrameArgs a, bool fast, const WorkspaceObject& ws, hipStream
     else      { if (fast) hipLaunchKernelGGL((march_defer<false, true>), grid, block, 0, st, a);
                 else hipLaunchKernelGGL((march_defer<false, false>), grid, block, 0, st, a); }
     RRT_HIP(hipGetLastError());
-    if (fast) hipLaunchKernelGGL((eval_sample_rows<true>), dim3(2048), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((eval_sample_rows<false>), dim3(2048), dim3(256), 0, st, a);
+#define RRT_EVAL(F, L) hipLaunchKernelGGL((eval_sample_rows<F, L>), dim3(2048), dim3(256), 0, st, a)
+    if (fast) { if (lut) RRT_EVAL(true, true); else RRT_EVAL(true, false); }
+    else      { if (lut) RRT_EVAL(false, true); else RRT_EVAL(false, false); }
+#undef RRT_EVAL
     RRT_HIP(hipGetLastError());
-    if (spin) { if (fast) hipLaunchKernelGGL((composite_and_shade<true, true>), grid, block, 0, st, a);
-                else hipLaunchKernelGGL((composite_and_shade<true, false>), grid, block, 0, st, a); }
-    else      { if (fast) hipLaunchKernelGGL((composite_and_shade<false, true>), grid, block, 0, st, a);
-                else hipLaunchKernelGGL((composite_and_shade<false, false>), grid, block, 0, st, a); }
+#define RRT_COMP(S, F) do { if (lut) hipLaunchKernelGGL((composite_and_shade<S, F, true>), grid, block, 0, st, a); \
+                            else hipLaunchKernelGGL((composite_and_shade<S, F, false>), grid, block, 0, st, a); } while (0)
+    if (spin) { if (fast) RRT_COMP(true, true); else RRT_COMP(true, false); }
+    else      { if (fast) RRT_COMP(false, true); else RRT_COMP(false, false); }
+#undef RRT_COMP
     RRT_HIP(hipGetLastError());
     return RRT_OK;
 }
@@ -780,7 +978,8 @@ int launch_deferred(FrameArgs a, bool fast, const WorkspaceObject& ws, hipStream
  * 1/8 (1.04 M rays) 11.7 ms vs 6.8 ms. */
 constexpr long long kThreePassMaxRays = 1500000;
 
-int launch(const FrameArgs& a, bool vol, bool debug, bool fast, int workspace, int policy, hipStream_t st) {
+/* media: 0 = off, 1 = on, 2 = on with the lattice-hash tables (a.lut_*) */
+int launch(const FrameArgs& a, int media, bool debug, bool fast, int workspace, int policy, hipStream_t st) {
     dim3 block(kWGThreads);
     if (a.rows.n_local_rows == 0) return RRT_OK;
     if (workspace != 0) {
@@ -793,23 +992,22 @@ int launch(const FrameArgs& a, bool vol, bool debug, bool fast, int workspace, i
         }
         const long long rays = (long long)a.width * a.rows.n_local_rows;
         const bool want = policy == RRT_PATH_THREE_PASS || (policy == RRT_PATH_AUTO && rays <= kThreePassMaxRays);
-        if (vol && !debug && want) {
-            int rc = launch_deferred(a, fast, ws, st);
+        if (media != 0 && !debug && want && a.max_steps <= kThreePassMaxSteps) {
+            int rc = launch_deferred(a, fast, media == 2, ws, st);
             if (rc >= 0) return rc;
         }
     }
     const bool spin = a.spin != 0.0f;
     dim3 grid((a.width + kWGPixX - 1) / kWGPixX, (a.rows.n_local_rows + kWGPixY - 1) / kWGPixY);
-#define RRT_LAUNCH(S, V, D) do { if (fast) hipLaunchKernelGGL((raymarch_pixels<S, V, D, true>), grid, block, 0, st, a); \
-                                 else hipLaunchKernelGGL((raymarch_pixels<S, V, D, false>), grid, block, 0, st, a); } while (0)
-    if (debug) {
-        if (spin) { if (vol) RRT_LAUNCH(true, true, true); else RRT_LAUNCH(true, false, true); }
-        else      { if (vol) RRT_LAUNCH(false, true, true); else RRT_LAUNCH(false, false, true); }
-    } else {
-        if (spin) { if (vol) RRT_LAUNCH(true, true, false); else RRT_LAUNCH(true, false, false); }
-        else      { if (vol) RRT_LAUNCH(false, true, false); else RRT_LAUNCH(false, false, false); }
-    }
-#undef RRT_LAUNCH
+#define RRT_LAUNCH4(S, M, D, F) hipLaunchKernelGGL((raymarch_pixels<S, M, D, F>), grid, block, 0, st, a)
+#define RRT_LAUNCH3(S, M, D) do { if (fast) RRT_LAUNCH4(S, M, D, true); else RRT_LAUNCH4(S, M, D, false); } while (0)
+#define RRT_LAUNCH2(S, M) do { if (debug) RRT_LAUNCH3(S, M, true); else RRT_LAUNCH3(S, M, false); } while (0)
+#define RRT_LAUNCH1(S) do { if (media == 2) RRT_LAUNCH2(S, 2); else if (media == 1) RRT_LAUNCH2(S, 1); else RRT_LAUNCH2(S, 0); } while (0)
+    if (spin) RRT_LAUNCH1(true); else RRT_LAUNCH1(false);
+#undef RRT_LAUNCH1
+#undef RRT_LAUNCH2
+#undef RRT_LAUNCH3
+#undef RRT_LAUNCH4
     RRT_HIP(hipGetLastError());
     return RRT_OK;
 }
@@ -843,7 +1041,7 @@ const char* rrt_status_string(int s) {
         case RRT_ERR_INVALID_ARGUMENT: return "invalid argument";
         case RRT_ERR_NO_DEVICE: return "no HIP device";
         case RRT_ERR_HIP: return "HIP runtime error";
-        case RRT_ERR_BAD_HANDLE: return "bad sky handle";
+        case RRT_ERR_BAD_HANDLE: return "bad handle (sky, workspace or noise table)";
         case RRT_ERR_OUT_OF_MEMORY: return "out of memory";
         default: return "unknown status";
     }
@@ -926,23 +1124,55 @@ int rrt_workspace_create(size_t bytes, int* out) {
     return RRT_OK;
 }
 
-/* One lazily created pool per device for callers that have nowhere to keep one (the C++ drop-in wrapper).
- * Not for concurrent use from several streams. */
-int rrt_default_workspace(size_t bytes_if_absent, int* out) {
-    if (!out) return RRT_ERR_INVALID_ARGUMENT;
-    static std::mutex mu;
-    static std::unordered_map<int, int> per_device;
-    int dev = 0;
-    RRT_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = per_device.find(dev);
-    if (it != per_device.end()) { *out = it->second; return RRT_OK; }
-    int id = 0;
-    int rc = rrt_workspace_create(bytes_if_absent, &id);
-    if (rc != RRT_OK) return rc;
-    per_device[dev] = id;
-    *out = id;
+/* Parameters of the reference-signature entry point launch_raymarch() (include/raymarcher.h), which has no
+ * parameter for them: config.h defaults until the application says otherwise.  Nothing is allocated here --
+ * a workspace or noise table named in the defaults is created (and destroyed) by the caller. */
+std::mutex g_defaults_mu;
+rrt_params g_defaults;
+bool g_defaults_set = false;
+
+int rrt_set_launch_defaults(const rrt_params* prm) {
+    std::lock_guard<std::mutex> lk(g_defaults_mu);
+    if (!prm) { g_defaults_set = false; return RRT_OK; }
+    if (prm->max_steps < 0 || prm->sky_frac_bits < 0 || prm->sky_frac_bits > 16 || !(prm->spin == prm->spin) ||
+        (prm->arith_mode != RRT_ARITH_STRICT && prm->arith_mode != RRT_ARITH_FAST) || prm->workspace < 0 ||
+        prm->path_policy < RRT_PATH_AUTO || prm->path_policy > RRT_PATH_THREE_PASS || prm->noise_table < 0)
+        return RRT_ERR_INVALID_ARGUMENT;
+    g_defaults = *prm;
+    g_defaults_set = true;
     return RRT_OK;
+}
+
+int rrt_get_launch_defaults(rrt_params* out) {
+    if (!out) return RRT_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(g_defaults_mu);
+    if (g_defaults_set) { *out = g_defaults; return RRT_OK; }
+    return rrt_params_default(out);
+}
+
+/* launch_raymarch() as the reference spells it, minus the C++ types: cam12 = pos, forward, right, up;
+ * effects36 = the 36 bytes of struct CameraEffects.  Asynchronous on the null stream.  The reference's
+ * launcher reports nothing (src/raymarcher.cu:176-180); this one returns the status and, the first time a
+ * launch fails, says why on stderr. */
+int rrt_launch_raymarch_compat(void* d_out_rgba8, int width, int height, float time, const float* cam12,
+                               rrt_sky_t sky, const void* effects36) {
+    if (!cam12 || !effects36) return RRT_ERR_INVALID_ARGUMENT;
+    rrt_camera c;
+    memcpy(&c, cam12, sizeof(c));
+    rrt_effects fx;
+    memcpy(&fx, effects36, sizeof(fx));
+    rrt_params prm;
+    rrt_get_launch_defaults(&prm);
+    const int rc = rrt_launch_raymarch(d_out_rgba8, width, height, time, &c, sky, &fx, &prm, nullptr);
+    if (rc != RRT_OK) {
+        static bool said = false;
+        if (!said) {
+            said = true;
+            fprintf(stderr, "launch_raymarch: %s%s%s (reported once)\n", rrt_status_string(rc),
+                    rc == RRT_ERR_HIP ? " -- " : "", rc == RRT_ERR_HIP ? rrt_last_hip_error() : "");
+        }
+    }
+    return rc;
 }
 
 int rrt_workspace_destroy(int id) {
@@ -987,6 +1217,71 @@ int rrt_workspace_read(int id, size_t offset, size_t bytes, void* host_dst) {
     return RRT_OK;
 }
 
+int rrt_noise_table_create(float t_max, int* out_id) {
+    if (!out_id || !(t_max >= 0.0f) || t_max > 1.0e4f) return RRT_ERR_INVALID_ARGUMENT;
+    NoiseTableObject nt;
+    memset(&nt, 0, sizeof(nt));
+    nt.t_max = t_max;
+    lut_boxes((double)t_max, nt.acc, nt.dust);
+    const LutBox* boxes[2] = {&nt.acc, &nt.dust};
+    size_t cells = 0;
+    for (const LutBox* b : boxes) {
+        const size_t n = (size_t)b->nx * b->ny * b->nz;
+        /* noise3d_lut multiplies with 24-bit operands and addresses records with 32-bit byte offsets */
+        if ((size_t)b->nx * b->ny >= ((size_t)1 << 23) || n >= ((size_t)1 << 28) || b->nz >= (1 << 23)) return RRT_ERR_INVALID_ARGUMENT;
+        cells += n;
+    }
+    nt.bytes = cells * sizeof(float4);
+    RRT_HIP(hipGetDevice(&nt.device));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&nt.d_cells), nt.bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(noise table)");
+    hipLaunchKernelGGL(build_noise_table, dim3(4096), dim3(256), 0, nullptr, nt.d_cells, nt.acc);
+    hipLaunchKernelGGL(build_noise_table, dim3(4096), dim3(256), 0, nullptr,
+                       nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(nt.d_cells); return hip_fail(e, "build_noise_table"); }
+    std::lock_guard<std::mutex> lk(g_nt_mu);
+    *out_id = g_nt_next++;
+    g_nt.emplace(*out_id, nt);
+    return RRT_OK;
+}
+
+int rrt_noise_table_destroy(int id) {
+    NoiseTableObject nt;
+    {
+        std::lock_guard<std::mutex> lk(g_nt_mu);
+        auto it = g_nt.find(id);
+        if (it == g_nt.end()) return RRT_ERR_BAD_HANDLE;
+        nt = it->second;
+        g_nt.erase(it);
+    }
+    hipError_t e = hipFree(nt.d_cells);
+    if (e != hipSuccess) return hip_fail(e, "hipFree(noise table)");
+    return RRT_OK;
+}
+
+int rrt_noise_table_info(int id, float* t_max, size_t* bytes, int* boxes12) {
+    std::lock_guard<std::mutex> lk(g_nt_mu);
+    auto it = g_nt.find(id);
+    if (it == g_nt.end()) return RRT_ERR_BAD_HANDLE;
+    const NoiseTableObject& nt = it->second;
+    if (t_max) *t_max = nt.t_max;
+    if (bytes) *bytes = nt.bytes;
+    if (boxes12) { memcpy(boxes12, &nt.acc, sizeof(LutBox)); memcpy(boxes12 + 6, &nt.dust, sizeof(LutBox)); }
+    return RRT_OK;
+}
+
+/* boxes only (host arithmetic, no device): what rrt_noise_table_create(t_max) would allocate */
+int rrt_noise_table_plan(float t_max, size_t* bytes, int* boxes12) {
+    if (!(t_max >= 0.0f) || t_max > 1.0e4f) return RRT_ERR_INVALID_ARGUMENT;
+    LutBox a, d;
+    lut_boxes((double)t_max, a, d);
+    if (bytes) *bytes = ((size_t)a.nx * a.ny * a.nz + (size_t)d.nx * d.ny * d.nz) * sizeof(float4);
+    if (boxes12) { memcpy(boxes12, &a, sizeof(LutBox)); memcpy(boxes12 + 6, &d, sizeof(LutBox)); }
+    return RRT_OK;
+}
+
 int rrt_launch_raymarch_rows(void* d_out_rows, int width, int height, int y0, int y1, float time,
                              const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx,
                              const rrt_params* prm, void* stream) {
@@ -994,12 +1289,12 @@ int rrt_launch_raymarch_rows(void* d_out_rows, int width, int height, int y0, in
     if (rc) return rc;
     if (y0 < 0 || y1 > height || y0 > y1) return RRT_ERR_INVALID_ARGUMENT;
     FrameArgs a;
-    bool vol, fast;
+    int media; bool fast;
     int wsid, policy;
-    rc = fill_args(a, vol, fast, wsid, policy, d_out_rows, width, height, time, cam, sky, fx, prm);
+    rc = fill_args(a, media, fast, wsid, policy, d_out_rows, width, height, time, cam, sky, fx, prm);
     if (rc) return rc;
     a.rows = RowMap{y1 - y0, y0, y1 - y0 > 0 ? y1 - y0 : 1, 0, 1};
-    return launch(a, vol, false, fast, wsid, policy, static_cast<hipStream_t>(stream));
+    return launch(a, media, false, fast, wsid, policy, static_cast<hipStream_t>(stream));
 }
 
 int rrt_launch_raymarch(void* d_out_rgba8, int width, int height, float time, const rrt_camera* cam,
@@ -1013,13 +1308,13 @@ int rrt_launch_raymarch_ex(void* d_out_rgba8, int width, int height, float time,
     int rc = check_common(d_out_rgba8, width, height, cam, fx, prm);
     if (rc) return rc;
     FrameArgs a;
-    bool vol, fast;
+    int media; bool fast;
     int wsid, policy;
-    rc = fill_args(a, vol, fast, wsid, policy, d_out_rgba8, width, height, time, cam, sky, fx, prm);
+    rc = fill_args(a, media, fast, wsid, policy, d_out_rgba8, width, height, time, cam, sky, fx, prm);
     if (rc) return rc;
     a.rows = RowMap{height, 0, height, 0, 1};
     if (dbg) a.dbg = *dbg;
-    return launch(a, vol, dbg != nullptr, fast, wsid, policy, static_cast<hipStream_t>(stream));
+    return launch(a, media, dbg != nullptr, fast, wsid, policy, static_cast<hipStream_t>(stream));
 }
 
 int rrt_tile_shard_rows(int height, int tile_rows, int shard, int n_shards, int* rows) {
@@ -1036,12 +1331,12 @@ int rrt_launch_raymarch_tiles(void* d_out_tiles, int width, int height, int tile
     if (rc) return rc;
     if (tile_rows <= 0 || n_shards <= 0 || shard < 0 || shard >= n_shards) return RRT_ERR_INVALID_ARGUMENT;
     FrameArgs a;
-    bool vol, fast;
+    int media; bool fast;
     int wsid, policy;
-    rc = fill_args(a, vol, fast, wsid, policy, d_out_tiles, width, height, time, cam, sky, fx, prm);
+    rc = fill_args(a, media, fast, wsid, policy, d_out_tiles, width, height, time, cam, sky, fx, prm);
     if (rc) return rc;
     a.rows = RowMap{shard_rows(height, tile_rows, shard, n_shards), 0, tile_rows, shard, n_shards};
-    return launch(a, vol, false, fast, wsid, policy, static_cast<hipStream_t>(stream));
+    return launch(a, media, false, fast, wsid, policy, static_cast<hipStream_t>(stream));
 }
 
 int rrt_assemble_tiles(void* d_frame, const void* d_tiles, int width, int height, int tile_rows, int shard,
@@ -1118,6 +1413,53 @@ int rrt_unit_sky_sample(int n, const float* dir, float off, rrt_sky_t sky, int f
     if (!sky_lookup(sky, so)) return RRT_ERR_BAD_HANDLE;
     SkyTex t{so.d_texels, so.w, so.h, frac_bits};
     return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_sky, g, b, 0, s, n, dir, off, t, out); });
+}
+
+int rrt_unit_disk_temperature(int n, const float* r, float* out, void* st) {
+    if (n > 0 && (!r || !out)) return RRT_ERR_INVALID_ARGUMENT;
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_disk_temperature, g, b, 0, s, n, r, out); });
+}
+int rrt_unit_smoothstep(int n, const float* e0, const float* e1, const float* x, float* out, void* st) {
+    if (n > 0 && (!e0 || !e1 || !x || !out)) return RRT_ERR_INVALID_ARGUMENT;
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_smoothstep, g, b, 0, s, n, e0, e1, x, out); });
+}
+int rrt_unit_postfx(int what, int n, const float* rgb, const float* uv, float param, float* out, void* st) {
+    if (what < 0 || what > 2) return RRT_ERR_INVALID_ARGUMENT;
+    if (n > 0 && (!out || (what != 2 && !uv) || (what != 0 && !rgb))) return RRT_ERR_INVALID_ARGUMENT;
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_postfx, g, b, 0, s, what, n, rgb, uv, param, out); });
+}
+int rrt_unit_rt_sample(int n, const float* d_disk, const float* d_cloud, const float* p, const float* vel, const float* h,
+                       float spin, float* rad, void* st) {
+    if (n > 0 && (!d_disk || !d_cloud || !p || !vel || !h || !rad)) return RRT_ERR_INVALID_ARGUMENT;
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_rt_sample, g, b, 0, s, n, d_disk, d_cloud, p, vel, h, spin, rad); });
+}
+int rrt_unit_noise3d_lut(int n, const float* p, int table, int which, float* out, unsigned* d_counts, void* st) {
+    if (n > 0 && (!p || !out)) return RRT_ERR_INVALID_ARGUMENT;
+    if (which < 0 || which > 1) return RRT_ERR_INVALID_ARGUMENT;
+    NoiseTableObject nt;
+    {
+        std::lock_guard<std::mutex> lk(g_nt_mu);
+        auto it = g_nt.find(table);
+        if (it == g_nt.end()) return RRT_ERR_BAD_HANDLE;
+        nt = it->second;
+    }
+    const NoiseLut L = which == 0 ? make_lut(nt.d_cells, nt.acc)
+                                  : make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust);
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_noise3d_lut, g, b, 0, s, n, p, L, out, d_counts); });
+}
+int rrt_unit_media_lut(int n, const float* p, float time, int table, float* out_disk, float* out_dust, unsigned* d_counts, void* st) {
+    if (n > 0 && (!p || !out_disk || !out_dust)) return RRT_ERR_INVALID_ARGUMENT;
+    NoiseTableObject nt;
+    {
+        std::lock_guard<std::mutex> lk(g_nt_mu);
+        auto it = g_nt.find(table);
+        if (it == g_nt.end()) return RRT_ERR_BAD_HANDLE;
+        nt = it->second;
+    }
+    if (!(time >= 0.0f && time <= nt.t_max)) return RRT_ERR_INVALID_ARGUMENT;
+    const NoiseLut la = make_lut(nt.d_cells, nt.acc);
+    const NoiseLut ld = make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust);
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_media_lut, g, b, 0, s, n, p, time, la, ld, out_disk, out_dust, d_counts); });
 }
 
 int rrt_selfcheck_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* st) {
@@ -1270,3 +1612,12 @@ int rrt_camera_from_angles(const float pos[3], float yaw, float pitch, rrt_camer
 }
 
 }  // extern "C"
+
+/* The reference's entry point as a linkable C++ symbol (include/raymarcher.h:19, src/raymarcher.cu:176-180),
+ * for translation units built against THIS repository's include/raymarcher.h (HIP vector types).  The twin
+ * under the reference's own mangled name (CUDA's `struct uchar4`) is csrc/rrt_compat.cpp. */
+#include "../../include/raymarcher.h"
+void launch_raymarch(uchar4* d_out, int w, int h, float time, CameraState cam, cudaTextureObject_t skyboxTex,
+                     CameraEffects effects) {
+    (void)rrt_launch_raymarch_compat(d_out, w, h, time, reinterpret_cast<const float*>(&cam), skyboxTex, &effects);
+}

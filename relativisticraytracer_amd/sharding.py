@@ -104,36 +104,47 @@ class FrameSharder:
         if self.collective:
             import torch.distributed as dist
             self.stage_cpu = dist.get_backend(group) == "gloo" and on_gpu
-            # Bring the communicator up with the collective the step uses (untimed, once).  `gather` is what
-            # the path needs (only rank 0 assembles); should a backend build lack it, every rank sees the
-            # same exception here and the step falls back to an all-gather of the same buffers.
+            # Bring the communicator up with the collectives the step uses (untimed, once).  Which collective the
+            # step will issue is decided COLLECTIVELY: every rank reports whether its probe worked and the ranks
+            # all-reduce (MIN) that flag, so that no rank can end up issuing a different collective from its
+            # peers (which would hang the job instead of failing it).
             probe = torch.zeros(256, dtype=torch.uint8, device="cpu" if self.stage_cpu else device)
-            try:
-                dist.gather(probe, [torch.zeros_like(probe) for _ in range(world)] if rank == 0 else None,
-                            dst=0, group=group)
-            except (RuntimeError, NotImplementedError):
+
+            def agree(ok):
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=probe.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                return bool(flag.item())
+
+            def try_collective(allgather, asyn):
+                try:
+                    if allgather:
+                        wk = dist.all_gather_into_tensor(
+                            torch.zeros(world * 256, dtype=torch.uint8, device=probe.device), probe, group=group,
+                            async_op=asyn)
+                    else:
+                        wk = dist.gather(probe, [torch.zeros_like(probe) for _ in range(world)] if rank == 0 else None,
+                                         dst=0, group=group, async_op=asyn)
+                    if asyn:
+                        wk.wait()
+                        if on_gpu:
+                            torch.cuda.synchronize()
+                    return True
+                except (RuntimeError, NotImplementedError):
+                    return False
+
+            # `gather` is what the path needs (only rank 0 assembles); a backend build without it falls back to
+            # an all-gather of the same buffers -- on every rank or on none.
+            if not agree(try_collective(False, False)):
+                if not agree(try_collective(True, False)):
+                    raise RuntimeError("FrameSharder: neither gather nor all_gather works on this process group")
                 self.use_allgather = True
                 if self.gathered_alls is None:
                     self.gathered_alls = [torch.zeros(world * self.n_bytes, dtype=torch.uint8, device=device)
                                           for _ in range(self.n_slots)]
-                dist.all_gather_into_tensor(torch.zeros(world * 256, dtype=torch.uint8, device=probe.device), probe,
-                                            group=group)
-            if self.pipeline:
-                # the same collective the pipelined step issues (async_op + wait), once, untimed; if the backend
-                # cannot do it every rank sees the failure here and the sharder runs one frame at a time instead
-                try:
-                    if self.use_allgather:
-                        wk = dist.all_gather_into_tensor(torch.zeros(world * 256, dtype=torch.uint8, device=probe.device),
-                                                         probe, group=group, async_op=True)
-                    else:
-                        wk = dist.gather(probe, [torch.zeros_like(probe) for _ in range(world)] if rank == 0 else None,
-                                         dst=0, group=group, async_op=True)
-                    wk.wait()
-                    if on_gpu:
-                        torch.cuda.synchronize()
-                except (RuntimeError, NotImplementedError, AttributeError):
-                    self.pipeline = False
-                    self.streams = None
+            if self.pipeline and not agree(try_collective(self.use_allgather, True)):
+                # no async collectives on this backend: one frame at a time, on every rank
+                self.pipeline = False
+                self.streams = None
         self.gathered_all = self.gathered_alls[0] if self.gathered_alls is not None else None
 
     def _on(self, slot):

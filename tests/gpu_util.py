@@ -24,19 +24,22 @@ def unit(name, *args):
     for a in args:
         if hasattr(a, "data_ptr"):
             conv.append(C.c_void_p(a.data_ptr()))
+        elif a is None:
+            conv.append(C.c_void_p(0))
         else:
             conv.append(a)
     conv.append(C.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(getattr(lib, "rrt_unit_" + name)(*conv), "rrt_unit_" + name)
 
 
-def render_gpu(w, h, spin, vol, cam, time, sky_tex, fx=None, debug=True, max_steps=2000, frac_bits=8, arith_mode=0):
+def render_gpu(w, h, spin, vol, cam, time, sky_tex, fx=None, debug=True, max_steps=2000, frac_bits=8, arith_mode=0,
+               noise_table=0):
     """Full-frame render through rrt_launch_raymarch(_ex); returns numpy arrays."""
     import torch
     import relativisticraytracer_amd as rrt
     fx = fx or rrt.CameraEffects()
     prm = rrt.RenderParams(spin=spin, volumetrics=vol, max_steps=max_steps, sky_frac_bits=frac_bits,
-                           arith_mode=arith_mode)
+                           arith_mode=arith_mode, noise_table=noise_table)
     out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
     res = {}
     if debug:
@@ -45,7 +48,8 @@ def render_gpu(w, h, spin, vol, cam, time, sky_tex, fx=None, debug=True, max_ste
                     steps=torch.zeros(n, dtype=torch.int32, device="cuda"),
                     hit=torch.zeros(n, dtype=torch.int32, device="cuda"),
                     pos=torch.zeros(n * 3, device="cuda"), vel=torch.zeros(n * 3, device="cuda"),
-                    rad=torch.zeros(n * 4, device="cuda"))
+                    rad=torch.zeros(n * 4, device="cuda"),
+                    lut_oob=torch.zeros(1, dtype=torch.int32, device="cuda"))
         rrt.launch_raymarch_debug(out, w, h, time, cam, sky_tex, fx, prm, **bufs)
         torch.cuda.synchronize()
         res = {k: v.cpu().numpy() for k, v in bufs.items()}

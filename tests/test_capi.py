@@ -26,7 +26,73 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.rrt_abi_version() == 1
+    assert lib.rrt_abi_version() == 2
+
+
+def test_library_exports_launch_raymarch_as_a_cpp_symbol():
+    """The reference's entry point is an ordinary C++ function (include/raymarcher.h:19, src/raymarcher.cu:176);
+    the library exports it under the reference's own Itanium name (CUDA's `struct uchar4`) and under the name
+    this repository's include/raymarcher.h (HIP vector types) produces."""
+    import subprocess
+    from relativisticraytracer_amd import _lib
+    _lib.load()
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert " T _Z15launch_raymarchP6uchar4iif11CameraStatey13CameraEffects" in syms
+    assert " T _Z15launch_raymarchP15HIP_vector_typeIhLj4EEiif11CameraStatey13CameraEffects" in syms
+
+
+def test_launch_defaults_round_trip_without_a_device():
+    import relativisticraytracer_amd as rrt
+    d = rrt.get_launch_defaults()
+    assert (d.spin, d.max_steps, d.volumetrics, d.workspace, d.noise_table) == (0.0, 2000, 1, 0, 0)
+    rrt.set_launch_defaults(rrt.RenderParams(spin=0.9, max_steps=1234))
+    d = rrt.get_launch_defaults()
+    assert abs(d.spin - 0.9) < 1e-7 and d.max_steps == 1234
+    with pytest.raises(rrt.RRTError):
+        rrt.set_launch_defaults(rrt.RenderParams(max_steps=-1))
+    rrt.set_launch_defaults(None)
+    assert rrt.get_launch_defaults().max_steps == 2000
+
+
+def test_noise_table_plan_covers_the_reachable_lattice():
+    """Host arithmetic only.  The boxes must contain the lattice cells of every table-served noise call; the
+    coordinates are re-derived here in float64 from densities.h for random in-zone points and times."""
+    import numpy as np
+    import relativisticraytracer_amd as rrt
+    t_max = 32.0
+    plan = rrt.NoiseTable.plan(t_max)
+    assert plan["bytes"] < 1 << 30
+    ax0, ay0, az0, anx, any_, anz = plan["accretion_box"]
+    dx0, dy0, dz0, dnx, dny, dnz = plan["dust_box"]
+    rng = np.random.default_rng(5)
+    n = 200000
+    rc = rng.uniform(10.0, 25.0, n); ang = rng.uniform(-np.pi, np.pi, n); t = rng.uniform(0, t_max, n)
+    # accretion: (rc cos, 4y, rc sin)*0.45 + (0, 0.35 t, 0), |y| < 4, 4 octaves of p*2.05+10
+    y = rng.uniform(-4, 4, n)
+    rot = ang - t * 3.5 * (10.0 / rc) ** 1.5
+    c = np.stack([rc * np.cos(rot) * 0.45, y * 4 * 0.45 + 0.35 * t, rc * np.sin(rot) * 0.45], 1)
+    for _ in range(4):
+        cell = np.floor(c)
+        for k, (o, m) in enumerate(((ax0, anx), (ay0, any_), (az0, anz))):
+            assert cell[:, k].min() >= o and cell[:, k].max() + 1 <= o + m - 1
+        c = c * 2.05 + 10
+    # dust: coords = (0.8 rc, 15 y, 10 (phi - t*omega)), |y| < 0.75; the warps move them by < 3*0.76 and 1.5*0.76
+    y = rng.uniform(-0.75, 0.75, n)
+    sc = np.stack([rc * 0.8, y * 15, (ang - t * (10.0 / rc) ** 1.5) * 10], 1)
+    w = rng.uniform(-0.76, 0.76, (n, 3))
+    fams = [sc * 0.15 + np.array(o) for o in ((0, 0, 0), (1, 2, 3), (4, 5, 6))]
+    fams += [(sc + 3 * w) * 0.4 + np.array(o) for o in ((0, 0, 0), (2, 1, 0), (0, 3, 1))]
+    pts = []
+    for f in fams:
+        pts += [f, f * 2.05 + 10]
+    fc = sc + 1.5 * w
+    pts += [fc * 2.1 ** k for k in range(3)]
+    d = fc * 4 + np.stack([np.zeros(n), 0.5 * t, np.zeros(n)], 1)
+    pts += [d]
+    for c in pts:
+        cell = np.floor(c)
+        for k, (o, m) in enumerate(((dx0, dnx), (dy0, dny), (dz0, dnz))):
+            assert cell[:, k].min() >= o and cell[:, k].max() + 1 <= o + m - 1
 
 
 def test_struct_layouts_match_the_reference_structs():

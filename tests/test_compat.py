@@ -1,5 +1,6 @@
 """The C++ drop-in boundary: include/raymarcher.h + librrt_hip.so used the way the reference's
-src/main.cpp:467 uses its own header."""
+src/main.cpp:467 uses its own header -- and an object built against the REFERENCE's header linking
+against the same library (the reference's own mangled launch_raymarch symbol)."""
 import os
 import subprocess
 
@@ -8,6 +9,8 @@ import pytest
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 EXE = os.path.join(ROOT, "tests", "compat", "dropin_main")
+REF_EXE = os.path.join(ROOT, "tests", "compat", "ref_header_main")
+REF_INC = "/root/reference/include"
 
 
 def _build():
@@ -20,26 +23,65 @@ def _build():
     subprocess.run(cmd, check=True)
 
 
+def _cuda_inc():
+    import importlib.util
+    s = importlib.util.find_spec("triton")
+    return os.path.join(os.path.dirname(s.origin), "backends", "nvidia", "include") if s else ""
+
+
+def build_ref_header_main():
+    """Build container only: compile against the reference's include/raymarcher.h, link librrt_hip.so."""
+    from relativisticraytracer_amd import build
+    build.build_lib()
+    cmd = ["g++", "-std=c++17", "-O1", "-w", "-I" + _cuda_inc(), "-I" + REF_INC, "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "compat", "ref_header_main.cpp"),
+           "-L" + os.path.dirname(build.LIB), "-lrrt_hip", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + os.path.dirname(build.LIB) + ":/opt/rocm/lib", "-o", REF_EXE]
+    subprocess.run(cmd, check=True)
+
+
 def test_dropin_translation_unit_compiles_and_links():
     _build()
     assert os.path.exists(EXE)
 
 
-@pytest.mark.gpu
-def test_dropin_frame_equals_python_path():
+@pytest.mark.skipif(not os.path.isdir(REF_INC), reason="the reference is only present in the build container")
+def test_object_built_against_the_reference_header_links():
+    build_ref_header_main()
+    und = subprocess.run(["nm", "-u", REF_EXE], check=True, capture_output=True, text=True).stdout
+    assert "_Z15launch_raymarchP6uchar4iif11CameraStatey13CameraEffects" in und
+
+
+def _python_checksum(w=64, h=36):
     import torch
     import relativisticraytracer_amd as rrt
-    if not os.path.exists(EXE):
-        _build()
-    out = subprocess.run([EXE, "64", "36"], check=True, capture_output=True, text=True).stdout.split()
     sw, sh = 256, 128
     j, i = np.meshgrid(np.arange(sh), np.arange(sw), indexing="ij")
     sky = np.stack([i & 255, (2 * j) & 255, (i ^ j) & 255, np.full_like(i, 255)], -1).astype(np.uint8)
     tex = rrt.SkyTexture(sky)
-    buf = torch.zeros(64 * 36 * 4, dtype=torch.uint8, device="cuda")
-    rrt.launch_raymarch(buf, 64, 36, 1.0, rrt.CameraState.default(), tex, rrt.CameraEffects())
+    buf = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    rrt.launch_raymarch(buf, w, h, 1.0, rrt.CameraState.default(), tex, rrt.CameraEffects())
     torch.cuda.synchronize()
     s = 1469598103934665603
     for b in buf.cpu().numpy().tolist():
         s = ((s ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
-    assert out[-1] == f"fnv1a64={s:016x}"
+    return f"fnv1a64={s:016x}"
+
+
+@pytest.mark.gpu
+def test_dropin_frame_equals_python_path():
+    if not os.path.exists(EXE):
+        _build()
+    out = subprocess.run([EXE, "64", "36"], check=True, capture_output=True, text=True).stdout.split()
+    assert out[-1] == _python_checksum()
+
+
+@pytest.mark.gpu
+def test_reference_header_object_renders_the_same_frame():
+    """The binary built here against the reference's header (it travels with the repository snapshot)."""
+    if not os.path.exists(REF_EXE):
+        if not os.path.isdir(REF_INC):
+            pytest.skip("ref_header_main was not built (needs the build container)")
+        build_ref_header_main()
+    out = subprocess.run([REF_EXE, "64", "36"], check=True, capture_output=True, text=True).stdout.split()
+    assert out[-1] == _python_checksum()

@@ -276,6 +276,76 @@ def test_three_pass_workspace_path_is_byte_identical(ctx):
         ws.destroy(); tiny.destroy()
 
 
+@pytest.mark.parametrize("name", ("G1", "G2", "G3", "G4", "G5", "K1", "K2", "R1"))
+def test_frames_against_the_reference_kernel(ctx, frames_ref, name):
+    """frames_ref.npz = the reference's OWN raymarch_kernel body compiled by g++ (glibc math): the HIP path takes
+    exactly the reference's number of RK4 steps for every ray (the geodesics contain no transcendentals) and its
+    bytes are within 1 LSB on all but a few pixels (libdevice / glibc / rrt_math.h differ by an ulp)."""
+    g, rrt, tex = ctx
+    w, h, spin, vol, t = frames_ref[f"{name}_scene"]
+    fl, fv = frames_ref[f"{name}_fx_flags"], frames_ref[f"{name}_fx_vals"]
+    fx = rrt.CameraEffects(useBloom=bool(fl[0]), useVignette=bool(fl[1]), useChromaticAberration=bool(fl[2]),
+                           useLensDistortion=bool(fl[3]), bloomThreshold=float(fv[0]), bloomIntensity=float(fv[1]),
+                           vignetteIntensity=float(fv[2]), caAmount=float(fv[3]), distortionAmount=float(fv[4]))
+    a = frames_ref[f"{name}_camera"]
+    cam = rrt.CameraState(a[0], a[1], a[2], a[3])
+    r = g.render_gpu(int(w), int(h), float(np.float32(spin)), int(vol), cam, float(np.float32(t)), tex, fx=fx)
+    assert np.array_equal(r["steps"], frames_ref[f"{name}_steps"].astype(np.int32))
+    d = np.abs(r["rgba8"].astype(int) - frames_ref[f"{name}_rgba8"].astype(int))
+    assert d.max() <= 1 and (d > 0).mean() <= 0.005
+
+
+def test_noise_table_path_is_byte_identical(ctx):
+    """rrt_params.noise_table: low-octave noise3D calls read their corner hashes from the lattice tables
+    whenever a wavefront's rays share a few cells.  Same bytes as the arithmetic path -- on 4K views where the
+    switches are on nearly everywhere (bench view, disk-grazing, from inside the disk), on small frames where
+    they are mostly off, through the three-pass path and shards; no read ever leaves a table box."""
+    import torch
+    g, rrt, tex = ctx
+    nt = rrt.NoiseTable(20.0)
+    ws = rrt.Workspace(3 << 30)
+    try:
+        views = [(3840, 2160, (0.0, 10.0, -60.0), 0.0, -10.0, 1.0),
+                 (3840, 2160, (4.2, 0.6, 4.2), -90.0, -5.7, 14.0),
+                 (1920, 1080, (35.0, 0.8, 10.0), -106.0, -1.2, 12.5),
+                 (1000, 700, (15.0, 3.0, -30.0), -26.6, -5.1, 6.0),
+                 (96, 54, (14.0, 0.05, 3.0), 200.0, 2.0, 19.5)]
+        for (w, h, pos, yaw, pitch, t) in views:
+            cam = rrt.CameraState.from_angles(pos, yaw, pitch); fx = rrt.CameraEffects(useChromaticAberration=True)
+            for spin, mode in ((0.9, 0), (0.0, 0), (0.9, 1)):
+                ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+                rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=spin, arith_mode=mode))
+                out = torch.zeros_like(ref)
+                rrt.launch_raymarch(out, w, h, t, cam, tex, fx,
+                                    rrt.RenderParams(spin=spin, arith_mode=mode, noise_table=nt.id))
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref), (w, h, pos, spin, mode)
+                if w * h <= 1920 * 1080:
+                    out.zero_()
+                    rrt.launch_raymarch(out, w, h, t, cam, tex, fx,
+                                        rrt.RenderParams(spin=spin, arith_mode=mode, noise_table=nt.id, workspace=ws.id,
+                                                         path_policy=2))
+                    torch.cuda.synchronize()
+                    assert torch.equal(out, ref), ("three-pass", w, h, pos, spin, mode, ws.stats())
+            # debug launch: counts table reads that had to be clamped
+            oob = torch.zeros(1, dtype=torch.int32, device="cuda")
+            out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+            rrt.launch_raymarch_debug(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id), lut_oob=oob)
+            torch.cuda.synchronize()
+            assert int(oob.item()) == 0, (w, h, pos)
+        # a time outside the table's range silently takes the arithmetic kernels
+        w, h = 160, 90
+        cam = rrt.CameraState.default(); fx = rrt.CameraEffects()
+        ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda"); out = torch.zeros_like(ref)
+        for t in (25.0, -1.0):
+            rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9))
+            rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id))
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), t
+    finally:
+        nt.destroy(); ws.destroy()
+
+
 def test_three_pass_full_size_and_heavy_view(ctx):
     """The pool at scale: the whole 4K bench frame (2.6 M rows, runs of up to 32 blocks) and a disk-skimming
     1080p view where single wavefronts own ~2000 rows; then the same heavy view through a pool that is too
@@ -364,7 +434,9 @@ def test_launch_argument_errors(ctx):
     assert lib.rrt_launch_raymarch(None, 4, 4, 0.0, C.byref(cam), tex.handle, C.byref(fx), None, None) == 1
     assert lib.rrt_launch_raymarch(p, 0, 4, 0.0, C.byref(cam), tex.handle, C.byref(fx), None, None) == 1
     assert lib.rrt_launch_raymarch(p, 4, 4, 0.0, C.byref(cam), 0, C.byref(fx), None, None) == 4      # bad handle
-    bad = rrt.RenderParams(); bad.reserved[0] = 7
+    bad = rrt.RenderParams(); bad.noise_table = -1
+    bad3 = rrt.RenderParams(); bad3.noise_table = 77
+    assert lib.rrt_launch_raymarch(p, 4, 4, 0.0, C.byref(cam), tex.handle, C.byref(fx), C.byref(bad3), None) == 4   # no such table
     bad2 = rrt.RenderParams(); bad2.arith_mode = 5
     assert lib.rrt_launch_raymarch(p, 4, 4, 0.0, C.byref(cam), tex.handle, C.byref(fx), C.byref(bad2), None) == 1
     assert lib.rrt_launch_raymarch(p, 4, 4, 0.0, C.byref(cam), tex.handle, C.byref(fx), C.byref(bad), None) == 1
@@ -473,6 +545,7 @@ def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
     g, rrt, tex = ctx
     rng = np.random.default_rng(20261004)
     ample, starved = rrt.Workspace(512 << 20), rrt.Workspace(13 << 20)     # 13 MiB: the smallest useful pool
+    nt = rrt.NoiseTable(30.0)
     try:
         overflowed = 0
         for case in range(int(os.environ.get("RRT_SWEEP_CASES", "14"))):      # soak: RRT_SWEEP_CASES=300
@@ -507,11 +580,15 @@ def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
             r = g.render_gpu(w, h, spin, 1, cam, t, tex, fx=fx)
             assert np.array_equal(r["steps"], o["steps"]) and np.array_equal(r["hit"], o["hit"]), tag
             assert np.array_equal(r["rgba8"], o["rgba8"]) and same_bits(r["ldr"], o["ldr"]), tag
+            r = g.render_gpu(w, h, spin, 1, cam, t, tex, fx=fx, noise_table=nt.id)       # same through the noise tables
+            assert np.array_equal(r["rgba8"], o["rgba8"]) and same_bits(r["ldr"], o["ldr"]), tag
+            assert int(r["lut_oob"][0]) == 0, tag
             want = torch.from_numpy(o["rgba8"].reshape(-1)).cuda()
             for pool in (ample, starved):
                 out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
                 rrt.launch_raymarch(out, w, h, t, cam, tex, fx,
-                                    rrt.RenderParams(spin=spin, workspace=pool.id, path_policy=2))
+                                    rrt.RenderParams(spin=spin, workspace=pool.id, path_policy=2,
+                                                     noise_table=nt.id if case % 2 else 0))
                 torch.cuda.synchronize()
                 assert torch.equal(out, want), (tag, pool.nbytes, pool.stats())
             overflowed += starved.stats()["overflow_waves"]
@@ -528,4 +605,4 @@ def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
             assert torch.equal(frame, want), (tag, n, R)
         assert overflowed > 0          # the starved pool did exercise the overflow route somewhere in the sweep
     finally:
-        ample.destroy(); starved.destroy()
+        ample.destroy(); starved.destroy(); nt.destroy()

@@ -134,6 +134,120 @@ def test_sky_sampler_bitexact(g, po, sky):
     tex.destroy()
 
 
+def test_disk_temperature_smoothstep_postfx_match_reference_vectors(g, po, units_ref):
+    """The small functions that round 1 only exercised inside frames, against the REFERENCE's own outputs
+    (units_ref.npz: densities.h:12-15, math_utils.h:45-48, post_processing.h:13-31 compiled by g++)."""
+    import torch
+    n = len(units_ref["temp_r"])
+    out = torch.empty(n, device="cuda")
+    g.unit("disk_temperature", n, g.dev(units_ref["temp_r"]), out)
+    got = g.host(out)
+    assert same_bits(got, po.units().disk_temperature(units_ref["temp_r"], po.MATH_PORTABLE))
+    ref = units_ref["disk_temperature"]                      # powf from glibc there, rrt_powf here
+    assert np.all(np.abs(got - ref) <= 1e-5 * np.abs(ref)) and np.array_equal(got == 0, ref == 0)
+    # smoothstep, lens, vignette, bloom: + - * / sqrt only -> bit-exact against the reference
+    g.unit("smoothstep", n, g.dev(units_ref["ss_e0"]), g.dev(units_ref["ss_e1"]), g.dev(units_ref["ss_x"]), out)
+    assert same_bits(g.host(out), units_ref["smoothstep"])
+    uv, rgb = g.dev(units_ref["uv"]), g.dev(units_ref["rgb"])
+    o2 = torch.empty(n * 2, device="cuda"); o3 = torch.empty(n * 3, device="cuda")
+    g.unit("postfx", 0, n, None, uv, 0.15, o2)
+    assert same_bits(g.host(o2).reshape(n, 2), units_ref["lens_k0.15"])
+    g.unit("postfx", 1, n, rgb, uv, 0.4, o3)
+    assert same_bits(g.host(o3).reshape(n, 3), units_ref["vignette_i0.4"])
+    g.unit("postfx", 2, n, rgb, None, 0.8, o3)
+    assert same_bits(g.host(o3).reshape(n, 3), units_ref["bloom_t0.8"])
+
+
+@pytest.mark.parametrize("spin", SPINS)
+def test_radiative_transfer_block_matches_oracle(g, po, units_ref, spin):
+    """raymarcher.cu:71-116 on its own (rrt_unit_rt_sample <-> rrto_rt_sample): every gate combination
+    (none / disk only / dust only / both), bit-exact in portable mode, <= 1e-5 relative vs libm."""
+    import torch
+    rng = np.random.default_rng(17)
+    n = len(units_ref["disk_p"])
+    p, vel = units_ref["disk_p"], units_ref["geo_v"]
+    d_disk = np.where(rng.random(n) < 0.3, 0.0005, np.exp(rng.uniform(np.log(0.0011), np.log(8.0), n))).astype(np.float32)
+    d_cloud = np.where(rng.random(n) < 0.3, 0.001, np.exp(rng.uniform(np.log(0.0011), np.log(12.0), n))).astype(np.float32)
+    h = (np.float32(0.3) * np.float32([0.1, 0.3])[rng.integers(0, 2, n)]).astype(np.float32)
+    rad0 = np.concatenate([rng.uniform(0, 2, (n, 3)), rng.uniform(0, 1, (n, 1))], 1).astype(np.float32)
+    rad = g.dev(rad0.reshape(-1).copy())
+    g.unit("rt_sample", n, g.dev(d_disk), g.dev(d_cloud), g.dev(p), g.dev(vel), g.dev(h), float(spin), rad)
+    got = g.host(rad).reshape(n, 4)
+    assert same_bits(got, po.rt_sample(d_disk, d_cloud, p, vel, h, spin, rad0, po.MATH_PORTABLE))
+    ref = po.rt_sample(d_disk, d_cloud, p, vel, h, spin, rad0, po.MATH_LIBM)
+    assert np.all(np.abs(got - ref) <= 1e-5 * np.abs(ref) + 1e-7)
+    untouched = (d_disk <= 0.001) & (d_cloud <= 0.001)
+    assert untouched.any() and np.array_equal(got[untouched], rad0[untouched])
+
+
+def test_noise_table_reads_equal_the_arithmetic_hash(g):
+    """noise3D through the lattice-hash table == noise3D computed, bit for bit, for points all over both boxes
+    (incl. their edges); points outside a box are counted and clamped, never read out of bounds."""
+    import torch
+    import relativisticraytracer_amd as rrt
+    nt = rrt.NoiseTable(8.0)
+    try:
+        info = nt.info()
+        rng = np.random.default_rng(23)
+        for which, key in ((0, "accretion_box"), (1, "dust_box")):
+            x0, y0, z0, nx, ny, nz = info[key]
+            n = 1 << 20
+            lo = np.array([x0, y0, z0], np.float64); span = np.array([nx - 1, ny - 1, nz - 1], np.float64)
+            pts = (lo + rng.uniform(0, 1, (n, 3)) * span).astype(np.float32)
+            pts[:8] = lo.astype(np.float32)                              # first cell
+            pts[8:16] = (lo + span - 1e-3).astype(np.float32)            # last cell
+            pts[16:24] = np.floor(pts[16:24])                            # exactly on lattice planes
+            pts = np.minimum(pts, (lo + span - 1e-3).astype(np.float32))
+            want = torch.empty(n, device="cuda"); got = torch.empty(n, device="cuda")
+            cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+            g.unit("noise3d", n, g.dev(pts), want)
+            g.unit("noise3d_lut", n, g.dev(pts), nt.id, which, got, cnt)
+            assert same_bits(g.host(got), g.host(want)), key
+            assert int(cnt.item()) == 0
+            far = (pts + np.float32(1e5)).astype(np.float32)             # way outside: clamped + counted
+            g.unit("noise3d_lut", 1024, g.dev(far[:1024]), nt.id, which, got, cnt)
+            assert int(cnt.item()) == 1024
+    finally:
+        nt.destroy()
+
+
+@pytest.mark.parametrize("t", (0.0, 1.0, 7.5))
+def test_density_functions_with_table_switches_equal_the_arithmetic_ones(g, po, t):
+    """The densities exactly as the render kernels evaluate them (early-out + wave-uniform table switches) on
+    wave-coherent sample points -- 64 neighbours a few hundredths of a unit apart, as the 8x8-pixel wavefronts
+    of a 4K frame produce -- so that the switches really are on; bits must equal the oracle's."""
+    import torch
+    import relativisticraytracer_amd as rrt
+    nt = rrt.NoiseTable(8.0)
+    try:
+        rng = np.random.default_rng(29)
+        waves = 4096
+        rc = rng.uniform(10.0, 25.0, waves); ang = rng.uniform(-np.pi, np.pi, waves)
+        yc = np.where(rng.random(waves) < 0.6, rng.uniform(-0.7, 0.7, waves), rng.uniform(-3.9, 3.9, waves))
+        centre = np.stack([rc * np.cos(ang), yc, rc * np.sin(ang)], 1)
+        spread = np.exp(rng.uniform(np.log(1e-3), np.log(0.3), waves))[:, None, None]
+        pts = (centre[:, None, :] + spread * rng.uniform(-0.5, 0.5, (waves, 64, 3))).reshape(-1, 3).astype(np.float32)
+        n = len(pts)
+        disk = torch.empty(n, device="cuda"); dust = torch.empty(n, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        rr = np.sqrt((pts.astype(np.float64) ** 2).sum(1))
+        in_cloud = (np.abs(pts[:, 1]) < 0.75) & (rr < 24.99)
+        in_disk = (np.abs(pts[:, 1]) < 4.0) & (rr < 29.99)
+        g.unit("media_lut", n, g.dev(pts), float(t), nt.id, disk, dust, cnt)
+        assert int(cnt.item()) == 0
+        want_disk = po.units().accretion_density(pts, t, po.MATH_PORTABLE)
+        want_dust = po.units().dust_density(pts, t, po.MATH_PORTABLE)
+        got_disk, got_dust = g.host(disk), g.host(dust)
+        # the render path's exact early-out returns 0 where the literal function returns a value <= 0.001
+        live = want_disk > 0.001
+        assert same_bits(got_disk[live & in_disk], want_disk[live & in_disk])
+        assert np.all(got_disk[~live & in_disk] <= 0.001)
+        assert same_bits(got_dust[in_cloud], want_dust[in_cloud])
+        assert (want_dust[in_cloud] > 0.001).mean() > 0.2 and live.mean() > 0.2
+    finally:
+        nt.destroy()
+
+
 def test_fast_sqrt_is_correctly_rounded_everywhere_it_is_used(g):
     """sqrt_rsq (rsq + Newton + residual fix-up) == IEEE sqrtf for EVERY float in [1, 2^64)."""
     import ctypes as C
