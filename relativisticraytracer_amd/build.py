@@ -63,6 +63,23 @@ def build_lib(force=False, extra_flags=(), verbose=False):
     return LIB
 
 
+def build_variant(name, extra_flags=()):
+    """dev builds for A/B timing: lib/variants/<name>.so with extra hipcc flags (tools/ab_views.py)."""
+    vdir = os.path.join(LIBDIR, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    compat_obj = os.path.join(LIBDIR, "rrt_compat.o")
+    if not os.path.exists(compat_obj):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-c", COMPAT_SRC, "-o", compat_obj], check=True)
+    obj = os.path.join(vdir, name + ".o")
+    subprocess.run([hipcc_path()] + [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + ["-c"] + SOURCES + ["-o", obj],
+                   check=True, cwd=vdir)
+    out = os.path.join(vdir, name + ".so")
+    subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", obj, compat_obj, "-o", out],
+                   check=True, cwd=vdir)
+    os.remove(obj)
+    return out
+
+
 HEADLESS_SRC = os.path.join(CSRC, "rrt_headless.cpp")
 HEADLESS_BIN = os.path.join(LIBDIR, "rrt_headless")
 
@@ -81,6 +98,9 @@ def build_headless(force=False):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+        sys.exit(0)
     extra = []
     if "--save-temps" in sys.argv:
         extra += ["-save-temps", "-Rpass-analysis=kernel-resource-usage"]

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""dev tool: per-opcode histogram of the hot march loop of a kernel, from the hipcc assembly listing.
+
+    python tools/isa_histogram.py [kernel-substring ...]    (default: the strict no-media / media / march_defer kernels)
+
+Compiles csrc/rrt_hip.hip with the build's own flags + -save-temps into a scratch directory, finds the
+outermost loop of each requested kernel (LLVM annotates every block with its loop header), splits its blocks
+into the STRAIGHT path (blocks reached by fall-through or by the loop's own control flow) and SIDE blocks
+(targets of a forward `s_cbranch_vccnz`: the guarded, practically never taken paths), and prints instruction
+counts by class and opcode.  The listing is the evidence for the "instructions per RK4 step" figures in
+DESIGN.md; the dynamic cross-check is SQ_INSTS_VALU / (waves x steps) from profiles/*_summary.json.
+"""
+import collections
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from relativisticraytracer_amd import build  # noqa: E402
+
+
+def listing():
+    d = tempfile.mkdtemp(prefix="rrt_isa_")
+    cmd = [build.hipcc_path()] + [f for f in build.HIPCC_FLAGS if f != "-shared"] + ["-save-temps", "-c"] + build.SOURCES + ["-o", os.path.join(d, "x.o")]
+    subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    f = [x for x in os.listdir(d) if x.endswith("gfx950.s")][0]
+    return open(os.path.join(d, f)).read().split("\n")
+
+
+def demangled(names):
+    out = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
+    return dict(zip(names, out))
+
+
+def classify(op):
+    if op.startswith("v_"):
+        if re.match(r"v_(rsq|rcp|sqrt|exp|log|sin|cos)_", op): return "VALU transcendental (half rate)"
+        if re.match(r"v_cmp|v_cmpx", op): return "VALU compare"
+        if re.match(r"v_cndmask|v_mov|v_readfirstlane|v_readlane|v_writelane", op): return "VALU select/move"
+        if re.match(r"v_(fma|fmac|mad|mac)_", op): return "VALU fma"
+        if re.match(r"v_mul_", op): return "VALU mul"
+        if re.match(r"v_(add|sub|subrev)_f", op): return "VALU add/sub f32"
+        return "VALU other"
+    if op.startswith("s_"):
+        if "branch" in op: return "SALU branch"
+        if op in ("s_nop", "s_waitcnt"): return "wait/nop"
+        return "SALU"
+    if op.startswith(("global_", "buffer_", "flat_", "scratch_")): return "VMEM"
+    if op.startswith("ds_"): return "LDS"
+    return "other"
+
+
+def analyse(src, name, pretty):
+    start = [i for i, l in enumerate(src) if l.startswith(name + ":")][0]
+    end = [i for i in range(start, len(src)) if src[i].strip().startswith(".Lfunc_end")][0]
+    body = src[start:end]
+    res = {}
+    for l in src[end:end + 80]:
+        m = re.search(r"; (NumVgprs|TotalNumSgprs|Occupancy|ScratchSize|codeLenInByte)\s*[:=]\s*(\d+)", l)
+        if m: res[m.group(1)] = int(m.group(2))
+    # blocks
+    blocks, cur = [], None
+    for l in body:
+        m = re.match(r"^(\.LBB\d+_\d+):\s*(;.*)?$", l)
+        if m:
+            cur = {"label": m.group(1), "comment": m.group(2) or "", "ins": []}
+            blocks.append(cur)
+            continue
+        t = l.split(";")[0].strip()
+        if cur is not None and not t and l.strip().startswith(";") and not cur["ins"]:
+            cur["comment"] += " " + l.strip()            # loop annotations follow the label on comment lines
+        if cur is not None and t and not t.startswith("."):
+            cur["ins"].append(t)
+    # outermost loop with the most instructions
+    hdrs = collections.Counter()
+    for b in blocks:
+        m = re.search(r"Header=(BB\d+_\d+) Depth=1", b["comment"])
+        if m: hdrs[m.group(1)] += len(b["ins"])
+    for b in blocks:
+        if re.search(r"Loop Header: Depth=1", b["comment"]): hdrs[b["label"][2:]] += len(b["ins"])
+    if not hdrs:
+        print(f"{pretty}: no loop found"); return
+    hdr = hdrs.most_common(1)[0][0]
+    loop = [b for b in blocks if b["label"] == ".L" + hdr or re.search(r"Header=%s Depth=1" % hdr, b["comment"])]
+    labels = {b["label"] for b in loop}
+    # STRAIGHT path = what a wavefront executes in a typical iteration: walk from the header, conditional
+    # branches fall through (LLVM lays the likely successor out next and moves guarded / expect-false paths
+    # out of line), unconditional branches are followed, until control returns to the header.
+    order = {b["label"]: k for k, b in enumerate(blocks)}
+    path, seen = [], set()
+    cur_i = order[".L" + hdr]
+    while True:
+        b = blocks[cur_i]
+        if b["label"] in seen or b["label"] not in labels: break
+        seen.add(b["label"]); path.append(b)
+        last = b["ins"][-1] if b["ins"] else ""
+        m = re.match(r"s_branch\s+(\.LBB\d+_\d+)", last)
+        if m:
+            if m.group(1) == ".L" + hdr: break
+            cur_i = order[m.group(1)]
+        else:
+            cur_i += 1
+            if cur_i >= len(blocks): break
+    straight = path
+    sideb = [b for b in loop if b["label"] not in seen]
+    print(f"== {pretty}")
+    print(f"   registers: {res.get('NumVgprs')} VGPR, {res.get('TotalNumSgprs')} SGPR, occupancy {res.get('Occupancy')} waves/SIMD, "
+          f"scratch {res.get('ScratchSize')} B, code {res.get('codeLenInByte')} B")
+    for title, bl in (("straight path of the march loop (one RK4 step" + (", media blocks included" if len(loop) > 60 else "") + ")", straight),
+                      ("blocks of the loop off that path (guarded fall-backs: a stage radius < 1, r2 not >= 1; lanes leaving)", sideb)):
+        ins = [t.split()[0] for b in bl for t in b["ins"]]
+        cls = collections.Counter(classify(o) for o in ins)
+        ops = collections.Counter(o for o in ins)
+        valu = sum(v for k, v in cls.items() if k.startswith("VALU"))
+        slots = valu + cls.get("VALU transcendental (half rate)", 0)
+        print(f"   {title}: {len(bl)} blocks, {len(ins)} instructions, {valu} VALU ({slots} issue slots counting half-rate ops twice)")
+        for k, v in sorted(cls.items(), key=lambda kv: -kv[1]):
+            print(f"      {k:34s} {v:5d}")
+        if bl is straight:
+            print("      opcodes: " + ", ".join(f"{o} {n}" for o, n in ops.most_common(40)))
+    print()
+
+
+def main():
+    src = listing()
+    names = [l.split(":")[0] for l in src if re.match(r"^_ZN12_GLOBAL__N_1\w+:", l)]
+    dm = demangled(names)
+    want = sys.argv[1:] or ["raymarch_pixels<true, 0, false, false>", "raymarch_pixels<false, 0, false, false>",
+                            "raymarch_pixels<true, 1, false, false>", "raymarch_pixels<true, 2, false, false>",
+                            "march_defer<true, false>", "raymarch_pixels<true, 0, false, true>"]
+    for w in want:
+        for n in names:
+            if w in dm[n]:
+                analyse(src, n, dm[n].split("(")[1].split("::")[-1] if "anonymous" in dm[n] else dm[n])
+
+
+if __name__ == "__main__":
+    main()

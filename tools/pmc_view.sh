@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 view=$1; vol=$2; shift; shift
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/pmcv
-rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmcv -- python3 $R/tools/one_view.py $view $vol 2 > /tmp/pmcv.txt 2>&1
+timeout -k 10 150 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmcv -- python3 $R/tools/one_view.py $view $vol 2 > /tmp/pmcv.txt 2>&1
 python3 - "$view" "$vol" <<'PY'
 import csv, glob, sys
 f = glob.glob("/tmp/pmcv/**/*counter_collection.csv", recursive=True)[0]
