@@ -38,7 +38,17 @@ def ops_per_ray(steps, noise, dens, samples):
     return 297.0 * steps + 223.0 * noise + 60.0 * dens + 40.0 * samples + 150.0
 
 
-def cpu_baseline(width, height, spin, stride, sky):
+def source_hash():
+    """sha256 over the kernel sources: ties a measured-traffic record (profiles/hbm_traffic.json) to the build
+    it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("rrt_hip.hip", "rrt_device.h", "rrt_math.h"):
+        h.update(open(os.path.join(ROOT, "relativisticraytracer_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(width, height, spin, stride, sky, cam_arr=None, time_=1.0):
     """Oracle (OpenMP, libm) on pixels (x, y) with x % stride == y % stride == 0 of the same frame."""
     import numpy as np
     from oracle import pyoracle as po
@@ -52,12 +62,12 @@ def cpu_baseline(width, height, spin, stride, sky):
                 cpu_model = ln.split(":", 1)[1].strip(); break
     except OSError:
         pass
-    a = rrt.CameraState.default().as_array()
+    a = cam_arr if cam_arr is not None else rrt.CameraState.default().as_array()
     cam = po.camera(a[0], a[1], a[2], a[3])
     prm = po.default_params(spin=spin)
     nthreads = po.max_threads()
     t0 = time.perf_counter()
-    r = po.render(cam, po.default_effects(), prm, 1.0, width, height, sky, stride=(stride, stride),
+    r = po.render(cam, po.default_effects(), prm, time_, width, height, sky, stride=(stride, stride),
                   want=("diag",), n_threads=nthreads)
     dt = time.perf_counter() - t0
     sel = np.zeros((height, width), bool); sel[::stride, ::stride] = True
@@ -104,6 +114,8 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=16)
     ap.add_argument("--cpu-stride", type=int, default=8, help="CPU baseline sample stride (0 = skip)")
     ap.add_argument("--no-fast", action="store_true", help="skip the informational RRT_ARITH_FAST leg")
+    ap.add_argument("--no-noise-table", action="store_true", help="hash every noise3D corner arithmetically (no lattice tables)")
+    ap.add_argument("--no-heavy", action="store_true", help="skip the informational heavy-view leg")
     ap.add_argument("--workspace-gib", type=int, default=16,
                     help="per-rank pool for the three-pass path (N > 1), split between the two frames in flight")
     args = ap.parse_args()
@@ -151,7 +163,14 @@ def main():
     pools = ([rrt.Workspace((args.workspace_gib << 30) // n_slots) for _ in range(n_slots)]
              if (world > 1 and args.workspace_gib > 0) else [])
     ws = pools[0] if pools else None
+    # Lattice-hash tables for the volumetric noise: built once (like the sky upload: a resident input, outside the
+    # timed region), camera- and time-independent within [0, t_max]; same bytes with or without them.
+    t_build0 = time.perf_counter()
+    ntab = None if args.no_noise_table else rrt.NoiseTable(32.0)
+    torch.cuda.synchronize()
+    table_build_ms = (time.perf_counter() - t_build0) * 1e3
     prms = [rrt.RenderParams(spin=args.spin, volumetrics=1, workspace=pools[j].id if pools else 0,
+                             noise_table=ntab.id if ntab else 0,
                              path_policy=int(os.environ.get("RRT_PATH_POLICY", "0"))) for j in range(n_slots)]
 
     kernel_ms = []
@@ -216,7 +235,7 @@ def main():
     # is measured right here on the full-size frame.
     fast = None
     if world == 1 and not args.no_fast:
-        prm_f = rrt.RenderParams(spin=args.spin, volumetrics=1, arith_mode=1)
+        prm_f = rrt.RenderParams(spin=args.spin, volumetrics=1, arith_mode=1, noise_table=ntab.id if ntab else 0)
         strict_frame = fs.frame.clone()
         buf = torch.zeros_like(strict_frame)
         for _ in range(max(1, args.warmup)):
@@ -234,6 +253,29 @@ def main():
                                     "bytes_off_by_more_than_1": int((d8 > 1).sum()), "max_byte_diff": int(d8.max())},
                 "note": "rrt_params.arith_mode=RRT_ARITH_FAST: fused multiply-adds and 1-ulp rsq in the RK4 "
                         "integrator; informational, not the parity path"}
+
+    # Informational third leg (single GPU): the same launch on a disk-heavy view -- the "Horizon Skimmer" keyframe
+    # (camera_paths.cpp:62) from inside the disk, where media sampling is ~40 % of the work -- strict arithmetic,
+    # with and without the noise tables.  The headline `value` is the BASELINE view above.
+    heavy = None
+    if world == 1 and not args.no_heavy:
+        hcam = rrt.CameraState.from_angles((4.2, 0.6, 4.2), -90.0, -5.7)
+        ht = 14.0
+        hbuf = torch.zeros(h * w * 4, dtype=torch.uint8, device=dev)
+        res = {}
+        for tag, tab in (("arithmetic_noise", 0), ("noise_table", ntab.id if ntab else 0)):
+            if tag == "noise_table" and not ntab:
+                continue
+            hp = rrt.RenderParams(spin=args.spin, volumetrics=1, noise_table=tab)
+            rrt.launch_raymarch(hbuf, w, h, ht, hcam, tex, fx, hp)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(max(2, args.steps // 2)):
+                rrt.launch_raymarch(hbuf, w, h, ht, hcam, tex, fx, hp)
+            torch.cuda.synchronize()
+            hms = (time.perf_counter() - t1) / max(2, args.steps // 2) * 1e3
+            res[tag] = {"ms_per_step": round(hms, 3), "Mrays_per_s": round(w * h / hms / 1e3, 3), "fps": round(1e3 / hms, 3)}
+        heavy = {"view": "Horizon Skimmer key (4.2, 0.6, 4.2) yaw -90 pitch -5.7, t=14.0, same size / spin / effects", **res}
 
     if rank == 0:
         rays = w * h
@@ -255,15 +297,31 @@ def main():
         opr = ops_per_ray(means["steps"], means["n_noise"], means["n_dens"], means["n_samples"])
         tops = opr * my_rays / (k_ms * 1e-3) / 1e12
         hbm_gbs = ALGO_BYTES_PER_RAY * my_rays / (k_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, tools/profile_round.sh),
+        # which cannot run inside this process.  The record is only used when it was measured on THIS build
+        # (hash of the kernel sources) and workload; otherwise `traffic` is null rather than stale.
+        traffic, traffic_note = None, "not measured for this build: run tools/profile_round.sh + tools/summarize_profile.py"
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1:
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == f"{w}x{h}_a{args.spin:g}_vol" and world == 1:
+                if tj.get("workload") == f"{w}x{h}_a{args.spin:g}_vol" and tj.get("source_hash") == source_hash():
                     traffic = tj.get("bytes_per_launch")
+                    traffic_note = "rocprofv3 PMC, " + str(tj.get("from", "profiles/"))
+                else:
+                    traffic_note = "profiles/hbm_traffic.json is from another build or workload; not used"
             except Exception:
                 traffic = None
+        if heavy is not None and args.cpu_stride > 0:
+            # per-ray work of the heavy view from a small oracle sample (exact counts, like the headline's)
+            _, hm = cpu_baseline(w, h, args.spin, 96, sky_np, cam_arr=rrt.CameraState.from_angles((4.2, 0.6, 4.2), -90.0, -5.7).as_array(),
+                                 time_=14.0)
+            heavy["per_ray_means"] = {k: round(v, 2) for k, v in hm.items()}
+            heavy["ops_per_ray"] = round(ops_per_ray(hm["steps"], hm["n_noise"], hm["n_dens"], hm["n_samples"]), 1)
+            for tag in ("arithmetic_noise", "noise_table"):
+                if tag in heavy:
+                    heavy[tag]["valu_roofline_frac"] = round(heavy["ops_per_ray"] * rays / (heavy[tag]["ms_per_step"] * 1e-3) / 1e12
+                                                             / VALU_PEAK_TOPS, 4)
         line = {
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -276,10 +334,13 @@ def main():
                        "parallelism": (f"rowtiles{R}x{world}" + (", two frames in flight (render k+1 overlaps gather/assemble of k)" if fs.pipeline else ""))
                                       if world > 1 else "single",
                        "path": ("auto: three-pass below 1.5 M rays per launch, %d GiB pool" % args.workspace_gib) if ws else "single kernel",
+                       "noise_table": ("lattice-hash tables, t_max 32 s, %.0f MB, built once in %.1f ms (outside the timed region)"
+                                       % (ntab.info()["bytes"] / 1e6, table_build_ms)) if ntab else "none (arithmetic hash)",
                        "dist_backend": (backend + (" (RCCL)" if backend == "nccl" else " (rehearsal: ranks share a card)")) if world > 1 else None,
                        "comm_ranks": dist.get_world_size() if world > 1 else 1},
             "roofline": {"bound": "valu", "achieved": round(tops, 3), "peak": round(VALU_PEAK_TOPS, 2),
                          "unit": "TFLOP/s", "frac": round(tops / VALU_PEAK_TOPS, 4), "traffic": traffic,
+                         "traffic_note": traffic_note,
                          "frac_of_fma_peak_157.3": round(tops / 157.3, 4),
                          "kernel": "raymarch_pixels", "kernel_ms": round(k_ms, 3),
                          "ops_per_ray": round(opr, 1), "per_ray_means": {k: round(v, 2) for k, v in means.items()},
@@ -291,6 +352,7 @@ def main():
                                  "note": "algorithmic 52 B/ray; the path is not HBM-bound"}},
             "cpu_baseline": cpu,
             "fast_mode": fast,
+            "heavy_view": heavy,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -298,6 +360,8 @@ def main():
         dist.destroy_process_group()
     for p in pools:
         p.destroy()
+    if ntab:
+        ntab.destroy()
     tex.destroy()
 
 

@@ -85,13 +85,13 @@ HEADLESS_BIN = os.path.join(LIBDIR, "rrt_headless")
 
 
 def build_headless(force=False):
-    """The C++ headless driver (host code only: g++, links librrt_hip.so and the HIP runtime)."""
+    """The C++ headless driver (host code only: g++, links librrt_hip.so, the HIP runtime and RCCL)."""
     build_lib()
     if not force and os.path.exists(HEADLESS_BIN) and os.path.getmtime(HEADLESS_BIN) > max(
             os.path.getmtime(HEADLESS_SRC), os.path.getmtime(LIB)):
         return HEADLESS_BIN
     cmd = ["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", HEADLESS_SRC,
-           "-L" + LIBDIR, "-lrrt_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + LIBDIR + ":/opt/rocm/lib",
+           "-L" + LIBDIR, "-lrrt_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-Wl,-rpath," + LIBDIR + ":/opt/rocm/lib",
            "-o", HEADLESS_BIN]
     subprocess.run(cmd, check=True)
     return HEADLESS_BIN

@@ -157,7 +157,10 @@ RRT_DEV float noise3d_lut(const NoiseLut& L, v3 p, unsigned* oob) {
 /* Per-lane distance (in lattice cells at scale 1, x weighted 1/4: a 128-byte line holds 8 x-neighbours) of
  * this lane's noise-space point from the first active lane's; lut_fits(spread, s) is wave-uniform: at `s`
  * cells per unit all active lanes stay within kLutCells cells of each other. */
-constexpr float kLutCells = 4.0f;
+#ifndef RRT_LUT_CELLS
+#define RRT_LUT_CELLS 12.0f
+#endif
+constexpr float kLutCells = RRT_LUT_CELLS;
 RRT_DEV float lut_spread(v3 c) {
     const float fx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.x)));
     const float fy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c.y)));

@@ -5,9 +5,19 @@
 // (captureFrame, :85-97 -- here a raw RGBA stream, the bytes the reference pipes into ffmpeg).
 //
 //   rrt_headless --width 1000 --height 700 --frames 24 --path 0 --spin 0.9 --out frames.rgba [--sky-seed 1]
+//                [--gpus N] [--tile-rows 16] [--workspace-gib G] [--noise-table-tmax T | --no-noise-table]
 //
-// Single GPU; the multi-GPU driver is relativisticraytracer_amd/headless.py (torch.distributed + RCCL).
+// Multi-GPU (the reference is single-GPU): ONE process drives N devices.  ncclCommInitAll
+// gives one RCCL communicator per device; image tile t (rows [16t, 16t+16)) belongs to device t mod N; every
+// frame each device renders its tiles into a compact buffer (rrt_launch_raymarch_tiles), ONE grouped
+// ncclSend / ncclRecv exchange -- a gather over xGMI -- lands all shards in one allocation on device 0, and
+// device 0 scatters them into the bottom-up frame with one launch (rrt_assemble_all_tiles).  Two frames are in
+// flight: frame k lives on stream k mod 2 of every device (own tile / gather / frame buffers and own pool), so
+// the next frame's wavefronts fill the drain of this one's kernels and the exchange sits under marching.
+// The same scheme as relativisticraytracer_amd/sharding.py (one process per GPU over torch.distributed), which
+// bench.py uses; the bytes are identical (tests/test_headless.py).
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 
 #include <chrono>
 #include <cstdint>
@@ -36,7 +46,8 @@ std::vector<uint8_t> synthetic_sky(int w, int h, int seed) {
             auto tri = [](int64_t v) { int64_t m = v % 512; if (m < 0) m += 512; m -= 256; return m < 0 ? -m : m; };
             int64_t ti = tri(i * 4 * 256 / w), tj = tri(j * 2 * 256 / h);
             int64_t band = 96 - (j - h / 2 < 0 ? h / 2 - j : j - h / 2) * 96 * 6 / h;
-            if (band < 0) band = 0; if (band > 96) band = 96;
+            if (band < 0) band = 0;
+            if (band > 96) band = 96;
             int64_t r = 10 + ti * 30 / 256 + band * 2 / 3, g = 12 + tj * 26 / 256 + band / 2, b = 28 + (ti + tj) * 20 / 256 + band;
             uint32_t hsh = mix((uint64_t)(i + j * w + (int64_t)seed * 0x9E3779B1ll));
             if (hsh % 641u == 0) {
@@ -54,42 +65,113 @@ int fail(const char* what, int rc) {
     fprintf(stderr, "rrt_headless: %s: %s (%s)\n", what, rrt_status_string(rc), rrt_last_hip_error());
     return 1;
 }
+#define HIPCHK(call)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        if (e_ != hipSuccess) { fprintf(stderr, "rrt_headless: %s: %s\n", #call, hipGetErrorString(e_)); return 1; } \
+    } while (0)
+#define NCCLCHK(call)                                                                                          \
+    do {                                                                                                       \
+        ncclResult_t r_ = (call);                                                                              \
+        if (r_ != ncclSuccess) { fprintf(stderr, "rrt_headless: %s: %s\n", #call, ncclGetErrorString(r_)); return 1; } \
+    } while (0)
+
+constexpr int kSlots = 2;      // frames in flight
+
+struct Device {                // everything one GPU owns
+    int id = 0;
+    rrt_sky_t sky = 0;
+    int noise_table = 0;
+    int pool[kSlots] = {0, 0};
+    hipStream_t stream[kSlots] = {nullptr, nullptr};
+    void* tiles[kSlots] = {nullptr, nullptr};     // this device's shard of a frame
+    int shard_rows = 0;
+    ncclComm_t comm = nullptr;
+};
 
 }  // namespace
 
 int main(int argc, char** argv) {
     int w = 1000, h = 700, frames = 24, fps = 24, path = -1, sky_seed = 1, all_fx = 0, fast = 0;   // config.h:7-9
-    float spin = 0.0f;
+    int gpus = 1, tile_rows = 16, workspace_gib = 2, use_table = 1, force_collective = 0;
+    float spin = 0.0f, table_tmax = -1.0f;
     std::string out_path;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto val = [&](int& dst) { if (i + 1 < argc) dst = atoi(argv[++i]); };
         if (a == "--width") val(w); else if (a == "--height") val(h); else if (a == "--frames") val(frames);
         else if (a == "--fps") val(fps); else if (a == "--path") val(path); else if (a == "--sky-seed") val(sky_seed);
+        else if (a == "--gpus") val(gpus); else if (a == "--tile-rows") val(tile_rows); else if (a == "--workspace-gib") val(workspace_gib);
         else if (a == "--spin" && i + 1 < argc) spin = (float)atof(argv[++i]);
+        else if (a == "--noise-table-tmax" && i + 1 < argc) table_tmax = (float)atof(argv[++i]);
+        else if (a == "--no-noise-table") use_table = 0;
+        else if (a == "--force-collective") force_collective = 1;     // run the RCCL exchange even with one GPU (self-check)
         else if (a == "--out" && i + 1 < argc) out_path = argv[++i];
         else if (a == "--all-effects") all_fx = 1; else if (a == "--fast") fast = 1;
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
+    if (w <= 0 || h <= 0 || frames < 0 || fps <= 0 || gpus < 1 || tile_rows < 1) { fprintf(stderr, "bad arguments\n"); return 2; }
     int n_dev = 0, rc;
     if ((rc = rrt_device_count(&n_dev)) != RRT_OK) return fail("no GPU", rc);
+    if (gpus > n_dev) { fprintf(stderr, "rrt_headless: --gpus %d but %d device(s) visible\n", gpus, n_dev); return 2; }
+    const bool collective = gpus > 1 || force_collective;
 
-    std::vector<uint8_t> sky = synthetic_sky(2048, 1024, sky_seed);
-    rrt_sky_t tex = 0;
-    if ((rc = rrt_sky_create(sky.data(), 2048, 1024, &tex)) != RRT_OK) return fail("sky", rc);
+    // the recording clock (main.cpp:511-516) says which times the noise tables must cover
+    if (use_table && table_tmax < 0.0f) {
+        float t_end = 0.0f, unused = 0.0f;
+        rrt_recording_clock(frames, fps, &t_end, &unused);
+        table_tmax = t_end + 1.0f;
+    }
+
+    const std::vector<uint8_t> sky = synthetic_sky(2048, 1024, sky_seed);
     rrt_effects fx; rrt_effects_default(&fx);
     fx.use_chromatic_aberration = (uint8_t)all_fx;
-    rrt_params prm; rrt_params_default(&prm);
-    prm.spin = spin; prm.arith_mode = fast ? RRT_ARITH_FAST : RRT_ARITH_STRICT;
-    int ws = 0;
-    if (rrt_workspace_create((size_t)2 << 30, &ws) == RRT_OK) prm.workspace = ws;
 
-    void* d_out = nullptr;
-    const size_t bytes = (size_t)w * h * 4;
-    if (hipMalloc(&d_out, bytes) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 1; }
-    std::vector<uint8_t> host(bytes);
+    // ---- per-device resources
+    std::vector<Device> dev(gpus);
+    size_t shard_stride = 0;                       // bytes between shards in the gathered buffer
+    for (int d = 0; d < gpus; ++d) {
+        int rows = 0;
+        rrt_tile_shard_rows(h, tile_rows, d, gpus, &rows);
+        dev[d].shard_rows = rows;
+        if ((size_t)rows * w * 4 > shard_stride) shard_stride = (size_t)rows * w * 4;
+    }
+    shard_stride = (shard_stride + 255) & ~(size_t)255;
+    for (int d = 0; d < gpus; ++d) {
+        Device& D = dev[d];
+        D.id = d;
+        HIPCHK(hipSetDevice(d));
+        if ((rc = rrt_sky_create(sky.data(), 2048, 1024, &D.sky)) != RRT_OK) return fail("sky", rc);
+        if (use_table && (rc = rrt_noise_table_create(table_tmax, &D.noise_table)) != RRT_OK) return fail("noise table", rc);
+        for (int s = 0; s < kSlots; ++s) {
+            HIPCHK(hipStreamCreateWithFlags(&D.stream[s], hipStreamNonBlocking));
+            HIPCHK(hipMalloc(&D.tiles[s], shard_stride));
+            if (workspace_gib > 0 && (rc = rrt_workspace_create(((size_t)workspace_gib << 30) / kSlots, &D.pool[s])) != RRT_OK)
+                return fail("workspace", rc);
+        }
+    }
+    if (collective) {
+        std::vector<int> ids(gpus);
+        std::vector<ncclComm_t> comms(gpus);
+        for (int d = 0; d < gpus; ++d) ids[d] = d;
+        NCCLCHK(ncclCommInitAll(comms.data(), gpus, ids.data()));
+        for (int d = 0; d < gpus; ++d) dev[d].comm = comms[d];
+    }
+    // device 0: gathered shards + assembled frame, per slot; pinned host frames for the sink
+    HIPCHK(hipSetDevice(0));
+    void* gathered[kSlots] = {nullptr, nullptr};
+    void* frame[kSlots] = {nullptr, nullptr};
+    void* host[kSlots] = {nullptr, nullptr};
+    hipEvent_t done[kSlots];
+    const size_t frame_bytes = (size_t)w * h * 4;
+    for (int s = 0; s < kSlots; ++s) {
+        HIPCHK(hipMalloc(&gathered[s], shard_stride * gpus));
+        HIPCHK(hipMalloc(&frame[s], frame_bytes));
+        HIPCHK(hipEventCreateWithFlags(&done[s], hipEventDisableTiming));
+    }
     FILE* f = out_path.empty() ? nullptr : fopen(out_path.c_str(), "wb");
     if (!out_path.empty() && !f) { perror("fopen"); return 1; }
+    if (f) for (int s = 0; s < kSlots; ++s) HIPCHK(hipHostMalloc(&host[s], frame_bytes, hipHostMallocDefault));
 
     rrt_camera cam;
     const float start_pos[3] = {0.0f, 10.0f, -60.0f};
@@ -97,24 +179,80 @@ int main(int argc, char** argv) {
     const char* path_name = "";
     if (path >= 0 && (rc = rrt_path_info(path, &path_name, nullptr, nullptr)) != RRT_OK) return fail("path", rc);
 
+    // write frame `k`'s pixels once its copy has landed (called one frame late, so that the copy overlaps the next render)
+    auto deliver = [&](int slot) -> int {
+        if (!f) return 0;
+        HIPCHK(hipEventSynchronize(done[slot]));
+        if (fwrite(host[slot], 1, frame_bytes, f) != frame_bytes) fprintf(stderr, "Warning: Frame write incomplete\n");
+        return 0;
+    };
+
+    for (int d = 0; d < gpus; ++d) { HIPCHK(hipSetDevice(d)); HIPCHK(hipDeviceSynchronize()); }
     auto t0 = std::chrono::steady_clock::now();
     for (int k = 1; k <= frames; ++k) {
+        const int slot = k % kSlots;
         float sim_t = 0.0f, path_t = 0.0f;
         rrt_recording_clock(k, fps, &sim_t, &path_t);
         if (path >= 0 && (rc = rrt_path_camera_at(path, path_t, &cam)) != RRT_OK) return fail("camera", rc);
-        if ((rc = rrt_launch_raymarch(d_out, w, h, sim_t, &cam, tex, &fx, &prm, nullptr)) != RRT_OK) return fail("launch", rc);
-        if (f) {
-            if (hipMemcpy(host.data(), d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "copy failed\n"); return 1; }
-            if (fwrite(host.data(), 1, bytes, f) != bytes) { fprintf(stderr, "Warning: Frame write incomplete\n"); }
+        // slot reuse: frame k-2 used the same buffers; its host copy must have been written out
+        if (k > kSlots && deliver(slot)) return 1;
+        // 1. every device renders its tiles
+        for (int d = 0; d < gpus; ++d) {
+            Device& D = dev[d];
+            HIPCHK(hipSetDevice(d));
+            rrt_params prm; rrt_params_default(&prm);
+            prm.spin = spin; prm.arith_mode = fast ? RRT_ARITH_FAST : RRT_ARITH_STRICT;
+            prm.workspace = D.pool[slot]; prm.noise_table = D.noise_table;
+            void* dst = collective ? D.tiles[slot] : frame[slot];
+            if (collective) rc = rrt_launch_raymarch_tiles(dst, w, h, tile_rows, d, gpus, sim_t, &cam, D.sky, &fx, &prm, D.stream[slot]);
+            else rc = rrt_launch_raymarch(dst, w, h, sim_t, &cam, D.sky, &fx, &prm, D.stream[slot]);
+            if (rc != RRT_OK) return fail("launch", rc);
         }
+        // 2. one gather: every device sends its shard, device 0 receives all of them (its own included)
+        if (collective) {
+            NCCLCHK(ncclGroupStart());
+            for (int d = 0; d < gpus; ++d) {
+                const size_t bytes = (size_t)dev[d].shard_rows * w * 4;
+                if (bytes == 0) continue;
+                NCCLCHK(ncclSend(dev[d].tiles[slot], bytes, ncclUint8, 0, dev[d].comm, dev[d].stream[slot]));
+                NCCLCHK(ncclRecv(static_cast<uint8_t*>(gathered[slot]) + (size_t)d * shard_stride, bytes, ncclUint8, d, dev[0].comm,
+                                 dev[0].stream[slot]));
+            }
+            NCCLCHK(ncclGroupEnd());
+            // 3. device 0 scatters the shards into the bottom-up frame
+            HIPCHK(hipSetDevice(0));
+            if ((rc = rrt_assemble_all_tiles(frame[slot], gathered[slot], shard_stride, w, h, tile_rows, gpus, dev[0].stream[slot])) != RRT_OK)
+                return fail("assemble", rc);
+        }
+        // 4. hand the frame to the sink: asynchronous copy now, the write happens one frame later
+        HIPCHK(hipSetDevice(0));
+        if (f) HIPCHK(hipMemcpyAsync(host[slot], frame[slot], frame_bytes, hipMemcpyDeviceToHost, dev[0].stream[slot]));
+        HIPCHK(hipEventRecord(done[slot], dev[0].stream[slot]));
     }
-    if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "sync failed\n"); return 1; }
-    double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    // drain: the last min(frames, kSlots) frames, oldest first
+    for (int k = frames - kSlots + 1; k <= frames; ++k)
+        if (k >= 1 && deliver(k % kSlots)) return 1;
+    for (int d = 0; d < gpus; ++d) { HIPCHK(hipSetDevice(d)); HIPCHK(hipDeviceSynchronize()); }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (f) fclose(f);
-    printf("{\"frames\": %d, \"width\": %d, \"height\": %d, \"seconds\": %.4f, \"fps\": %.3f, \"Mrays_per_s\": %.3f, "
-           "\"path\": \"%s\", \"spin\": %g, \"arith_mode\": \"%s\"}\n",
-           frames, w, h, dt, frames / dt, (double)frames * w * h / dt / 1e6, path_name, spin, fast ? "fast" : "strict");
-    hipFree(d_out);
-    rrt_sky_destroy(tex);
+    printf("{\"frames\": %d, \"width\": %d, \"height\": %d, \"n_gpus\": %d, \"seconds\": %.4f, \"fps\": %.3f, \"Mrays_per_s\": %.3f, "
+           "\"path\": \"%s\", \"spin\": %g, \"arith_mode\": \"%s\", \"noise_table_tmax\": %g, \"collective\": \"%s\"}\n",
+           frames, w, h, gpus, dt, frames / dt, (double)frames * w * h / dt / 1e6, path_name, spin, fast ? "fast" : "strict",
+           use_table ? table_tmax : 0.0f, collective ? "rccl grouped send/recv gather" : "none");
+
+    for (int d = 0; d < gpus; ++d) {
+        Device& D = dev[d];
+        HIPCHK(hipSetDevice(d));
+        if (D.comm) ncclCommDestroy(D.comm);
+        for (int s = 0; s < kSlots; ++s) {
+            if (D.pool[s]) rrt_workspace_destroy(D.pool[s]);
+            (void)hipFree(D.tiles[s]);
+            (void)hipStreamDestroy(D.stream[s]);
+        }
+        if (D.noise_table) rrt_noise_table_destroy(D.noise_table);
+        rrt_sky_destroy(D.sky);
+    }
+    HIPCHK(hipSetDevice(0));
+    for (int s = 0; s < kSlots; ++s) { (void)hipFree(gathered[s]); (void)hipFree(frame[s]); if (host[s]) (void)hipHostFree(host[s]); }
     return 0;
 }

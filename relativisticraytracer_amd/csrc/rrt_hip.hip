@@ -351,46 +351,72 @@ __device__ __forceinline__ void march_radius(v3 rel_p, float& r2, float& r, floa
     }
 }
 
+/* One RK4 step of the march (integrate_rk4, integrators.h:23-59) from the loop-top radius of the pre-step
+ * position.  (A variant without the per-stage `r < 1` guards -- 5 fewer vector instructions per step, repeated
+ * with guards in the unreachable case -- was measured and dropped: the longer basic blocks it leaves let the
+ * scheduler interleave independent chains, and on gfx950 a VALU instruction issued 2-6 slots after its producer
+ * costs 10-15 % more than one issued right behind it; profiles/README.md, round 2.) */
+template <bool SPIN, bool FAST>
+__device__ __forceinline__ void march_step(v3& p, v3& vel, float h, float hh, float h6, float drag_c, float r2, float r, float y) {
+    if (FAST) integrate_rk4_fast<SPIN>(p, vel, h, hh, h6, drag_c, r2, y);
+    else integrate_rk4_r<SPIN>(p, vel, h, hh, h6, drag_c, r2, r, y);
+}
+
+/* Step size of raymarcher.cu:54-62 from the zone flags; h*0.5f is exact, h/6.0f is folded per value. */
+__device__ __forceinline__ void zone_step(bool near_bh, bool in_disk, float& h, float& hh, float& h6) {
+    h = near_bh ? kHNear : (in_disk ? kHDisk : kHVac);
+    hh = 0.5f * h;                                      /* == h * 0.5f of integrators.h:31, one multiply */
+    h6 = near_bh ? kHNear / 6.0f : (in_disk ? kHDisk / 6.0f : kHVac / 6.0f);
+}
+
 /* The whole march of one ray with the media sampled in line: raymarcher.cu:41-121.
- * MEDIA: 0 = densities read 0 ("skybox only"), 1 = full media, 2 = full media with the lattice-hash tables. */
+ * MEDIA: 0 = densities read 0 ("skybox only"), 1 = full media, 2 = full media with the lattice-hash tables.
+ * `i`: in = first step (0, or where a resumed ray stopped), out = steps taken.  When every lane starts at the
+ * same step the loop counter stays in a scalar register; the per-ray count is written once, at the exit. */
 template <bool SPIN, int MEDIA, bool FAST>
 __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel, Radiance& acc, bool& hit, int& i,
                                              unsigned* oob) {
-    for (; i < a.max_steps; ++i) {
+    int steps = i > a.max_steps ? i : a.max_steps;      /* if the loop runs out */
+    for (int k = i; k < a.max_steps; ++k) {
         const v3 rel_p = p;                             /* p - MASS_POS, MASS_POS = 0 */
         float r2, r, y;
         march_radius<FAST>(rel_p, r2, r, y);
-        if (r < kEventHorizon * 1.01f) { hit = true; acc.t = 0.0f; break; }
+        if (r < kEventHorizon * 1.01f) { hit = true; acc.t = 0.0f; steps = k; break; }
 
         const bool near_bh = r < 18.0f;
         const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
         const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
-        const float h = near_bh ? kHNear : (in_disk ? kHDisk : kHVac);
-        const float hh = near_bh ? kHNear * 0.5f : (in_disk ? kHDisk * 0.5f : kHVac * 0.5f);
-        const float h6 = near_bh ? kHNear / 6.0f : (in_disk ? kHDisk / 6.0f : kHVac / 6.0f);
+        float h, hh, h6;
+        zone_step(near_bh, in_disk, h, hh, h6);
 
-        if (FAST) integrate_rk4_fast<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, y);
-        else integrate_rk4_r<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, r, y);
+        march_step<SPIN, FAST>(p, vel, h, hh, h6, a.drag_c, r2, r, y);
 
         if (MEDIA != 0 && (in_disk || in_cloud)) {
             float d_disk = in_disk ? accretion_density<true, MEDIA == 2>(rel_p, a.time, a.lut_acc, oob) : 0.0f;
             float d_cloud = in_cloud ? dust_density<MEDIA == 2>(rel_p, a.time, a.lut_dust, oob) : 0.0f;
             accumulate_sample(acc, d_disk, d_cloud, rel_p, r, vel, h, a.spin);
         }
-        if (r > 250.0f && dot(rel_p, vel) > 0.0f) { ++i; break; }
+        if (r > 250.0f && dot(rel_p, vel) > 0.0f) { steps = k + 1; break; }
     }
+    i = steps;
 }
 
-/* Workgroup geometry of the per-ray kernels.  A wavefront always covers an 8x8 pixel tile, so its 64 rays
- * stay spatially coherent (similar step counts, similar zone entry).  RRT_WG_WAVES = 1: one wavefront per
- * workgroup (a CU slot is released as soon as that wave is done -- no waiting for three siblings);
- * 4: a 16x16 pixel block per 256-thread workgroup. */
+/* Workgroup geometry of the per-ray kernels.  A wavefront covers a compact kTileW x kTileH pixel tile (8x8
+ * unless RRT_TILE_W says otherwise), so its 64 rays stay spatially coherent: similar step counts, similar
+ * zone entry, and sample points that share lattice cells of the low noise octaves (which is what makes the
+ * noise tables pay).  RRT_WG_WAVES = 1: one wavefront per workgroup (a CU slot is released as soon as that wave
+ * is done -- no waiting for three siblings); 4: a 2x2 block of wave tiles per 256-thread workgroup. */
 #ifndef RRT_WG_WAVES
 #define RRT_WG_WAVES 1
 #endif
+#ifndef RRT_TILE_W
+#define RRT_TILE_W 8
+#endif
 constexpr int kWGWaves = RRT_WG_WAVES;
 constexpr int kWGThreads = 64 * kWGWaves;
-constexpr int kWGPixX = kWGWaves == 4 ? 16 : 8, kWGPixY = kWGWaves == 4 ? 16 : 8;
+constexpr int kTileW = RRT_TILE_W, kTileH = 64 / kTileW;
+static_assert(kTileW * kTileH == 64 && (kTileW & (kTileW - 1)) == 0, "a wave tile is 64 pixels, power-of-two wide");
+constexpr int kWGPixX = kWGWaves == 4 ? 2 * kTileW : kTileW, kWGPixY = kWGWaves == 4 ? 2 * kTileH : kTileH;
 
 /* Workgroups are dispatched in blockIdx order; the rows through the middle of the frame hold the
  * longest rays (shadow edge, disk), so row-blocks are visited from the middle outwards: mid, mid+1,
@@ -401,8 +427,8 @@ __device__ __forceinline__ int row_block() {
 }
 __device__ __forceinline__ bool lane_pixel(const FrameArgs& a, int& x, int& y, int& out_row) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    x = blockIdx.x * kWGPixX + (wave & 1) * 8 + (lane & 7);
-    const int lr = row_block() * kWGPixY + (wave >> 1) * 8 + (lane >> 3);
+    x = blockIdx.x * kWGPixX + (wave & 1) * kTileW + (lane & (kTileW - 1));
+    const int lr = row_block() * kWGPixY + (wave >> 1) * kTileH + lane / kTileW;
     return x < a.width && map_row(a.rows, a.height, lr, y, out_row);
 }
 /* max over the live lanes of a wave; lanes that are not executing contribute 0 */
@@ -465,9 +491,8 @@ __global__ __launch_bounds__(kWGThreads) __attribute__((amdgpu_num_sgpr(80))) vo
         const bool near_bh = r < 18.0f;
         const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
         const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
-        const float h = near_bh ? kHNear : (in_disk ? kHDisk : kHVac);
-        const float hh = near_bh ? kHNear * 0.5f : (in_disk ? kHDisk * 0.5f : kHVac * 0.5f);
-        const float h6 = near_bh ? kHNear / 6.0f : (in_disk ? kHDisk / 6.0f : kHVac / 6.0f);
+        float h, hh, h6;
+        zone_step(near_bh, in_disk, h, hh, h6);
 
         /* Both density functions return 0 unless the cylindrical radius rc = sqrtf(x*x + 0*0 + z*z) is in
          * [ISCO, DISK_OUT] (densities.h:21-22, :70-71); only those steps need a sample.  rc comes from
@@ -537,8 +562,7 @@ __global__ __launch_bounds__(kWGThreads) __attribute__((amdgpu_num_sgpr(80))) vo
             ++used;
         }
 
-        if (FAST) integrate_rk4_fast<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, yv);
-        else integrate_rk4_r<SPIN>(p, vel, h, hh, h6, a.drag_c, r2, r, yv);
+        march_step<SPIN, FAST>(p, vel, h, hh, h6, a.drag_c, r2, r, yv);
 
         if (need) {                                                /* pre-step position, post-step velocity */
             row_f[0] = rel_p.x; row_f[64] = rel_p.y; row_f[128] = rel_p.z;

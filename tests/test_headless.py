@@ -86,6 +86,49 @@ def test_cpp_and_python_drivers_write_the_same_frames(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cpp_driver_rccl_gather_path_writes_the_same_frames(tmp_path):
+    """rrt_headless is ONE process for N GPUs (ncclCommInitAll, grouped ncclSend/ncclRecv gather into device 0,
+    rrt_assemble_all_tiles, two frames in flight).  On the one-GPU box the same code runs over a one-rank
+    communicator (--force-collective): tiles -> RCCL exchange -> assemble must give the frames of the plain
+    single-GPU path, with and without the noise tables and the three-pass pool."""
+    from relativisticraytracer_amd import build
+    exe = build.build_headless()
+    base = ["--width", "160", "--height", "90", "--frames", "5", "--path", "0", "--spin", "0.9", "--all-effects"]
+    ref = tmp_path / "plain.rgba"
+    subprocess.run([exe] + base + ["--no-noise-table", "--workspace-gib", "0", "--out", str(ref)], check=True, capture_output=True)
+    want = open(ref, "rb").read()
+    assert len(want) == 5 * 160 * 90 * 4
+    for extra in (["--force-collective"], ["--force-collective", "--tile-rows", "7", "--workspace-gib", "1"],
+                  ["--force-collective", "--no-noise-table", "--workspace-gib", "0"], []):
+        out = tmp_path / "v.rgba"
+        r = subprocess.run([exe] + base + extra + ["--out", str(out)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        meta = json.loads(r.stdout.strip().splitlines()[-1])
+        assert meta["n_gpus"] == 1 and meta["frames"] == 5
+        assert ("rccl" in meta["collective"]) == ("--force-collective" in extra)
+        assert open(out, "rb").read() == want, extra
+    r = subprocess.run([exe] + base + ["--gpus", "99"], capture_output=True, text=True)
+    assert r.returncode == 2 and "device(s) visible" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` as the driver invokes it (no launcher): bench.py starts the two ranks itself as
+    child processes and relays rank 0's single JSON line.  On the one-GPU box the ranks share the card over gloo."""
+    env = dict(os.environ, RRT_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--width", "320", "--height", "180", "--steps", "2",
+                        "--warmup", "1", "--cpu-stride", "0", "--workspace-gib", "2"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["comm_ranks"] == 2
+    assert d["scaling"] == "strong" and d["value"] > 0
+
+
+@pytest.mark.gpu
 def test_two_ranks_pipelined_equal_one_rank(tmp_path):
     """Two ranks sharing the card (gloo rehearsal of the N > 1 path: interleaved tiles, two frames in flight,
     gather, assemble) write the same 5 frames as one rank."""

@@ -45,5 +45,17 @@ for name in ("fetch", "write", "sq"):
         n[r["Counter_Name"]] = n.get(r["Counter_Name"], 0) + 1
     for k in acc:
         out[k + "_per_launch"] = acc[k] / n[k]
+if "FETCH_SIZE_per_launch" in out and "WRITE_SIZE_per_launch" in out:
+    # HBM bytes per launch of the dominant kernel: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports
+    # half the bytes of wide reads (MI355X_MICROARCH.md, HBM) -> doubled (an upper bound for this kernel's narrow
+    # gather reads); the two counters come from separate --pmc passes.  Keyed on the kernel sources so that
+    # bench.py never reports it for another build.
+    sys.path.insert(0, ".")
+    import bench
+    traffic = {"workload": "3840x2160_a0.9_vol", "source_hash": bench.source_hash(),
+               "bytes_per_launch": (2 * out["FETCH_SIZE_per_launch"] + out["WRITE_SIZE_per_launch"]) * 1024,
+               "from": f"profiles/{tag}_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes",
+               "fetch_kb": out["FETCH_SIZE_per_launch"], "write_kb": out["WRITE_SIZE_per_launch"]}
+    json.dump(traffic, open("profiles/hbm_traffic.json", "w"), indent=1)
 json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
