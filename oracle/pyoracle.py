@@ -123,8 +123,11 @@ def max_threads():
 
 
 def render(cam, fx, prm, time, width, height, sky, rect=None, stride=(1, 1),
-           want=("rgba8",), n_threads=0):
-    """Render with the oracle.  Returns a dict of full-frame arrays (see rrt_oracle.h)."""
+           want=("rgba8",), n_threads=0, gates=None, gate_cap=8192):
+    """Render with the oracle.  Returns a dict of full-frame arrays (see rrt_oracle.h).
+    gates="record": also returns "gate_log" (n_samples, gate_cap) uint8 and "gate_count" (n_samples,) int32, the
+    hard-gate decisions of every rendered ray (row-major over the strided sample grid, top-down); gates=(gate_log, gate_count) replays recorded decisions instead of
+    evaluating the gates (rrto_render_gates)."""
     sky = np.ascontiguousarray(sky, dtype=np.uint8)
     sh, sw = sky.shape[:2]
     x0, y0, x1, y1 = rect if rect else (0, 0, width, height)
@@ -145,15 +148,29 @@ def render(cam, fx, prm, time, width, height, sky, rect=None, stride=(1, 1),
         out["vel"] = np.zeros((n, 3), np.float32); d.vel = _p(out["vel"])
         out["rad"] = np.zeros((n, 4), np.float32); d.rad = _p(out["rad"])
         dptr = C.byref(d)
-    rc = lib().rrto_render(C.byref(cam), C.byref(fx), C.byref(prm), _f(time), width, height,
-                           x0, y0, x1, y1, stride[0], stride[1],
-                           sky.ctypes.data_as(_u8p), sw, sh,
-                           rgba8.ctypes.data_as(_u8p) if rgba8 is not None else None,
-                           _p(ldr) if ldr is not None else None,
-                           _p(hdr) if hdr is not None else None,
-                           dptr, n_threads)
+    gmode, glog, gcnt = 0, None, None
+    if gates == "record":
+        gmode = 1
+        n_s = len(range(y0, y1, stride[1])) * len(range(x0, x1, stride[0]))     # logs are per rendered sample
+        glog = np.zeros((n_s, gate_cap), np.uint8); gcnt = np.zeros(n_s, np.int32)
+    elif gates is not None:
+        gmode = 2
+        glog = np.ascontiguousarray(gates[0], np.uint8); gcnt = np.array(gates[1], np.int32)
+        gate_cap = glog.shape[1]
+    fn = lib().rrto_render_gates
+    fn.restype = _i
+    rc = fn(C.byref(cam), C.byref(fx), C.byref(prm), _f(time), width, height,
+            x0, y0, x1, y1, stride[0], stride[1],
+            sky.ctypes.data_as(_u8p), sw, sh,
+            rgba8.ctypes.data_as(_u8p) if rgba8 is not None else None,
+            _p(ldr) if ldr is not None else None,
+            _p(hdr) if hdr is not None else None,
+            dptr, n_threads, gmode, glog.ctypes.data_as(_u8p) if glog is not None else None, int(gate_cap),
+            gcnt.ctypes.data_as(_ip) if gcnt is not None else None)
     if rc != 0:
         raise ValueError("rrto_render: bad arguments")
+    if gmode:
+        out["gate_log"], out["gate_count"] = glog, gcnt
     if rgba8 is not None:
         out["rgba8"] = rgba8
     if ldr is not None:

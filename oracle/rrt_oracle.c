@@ -39,7 +39,34 @@ typedef struct {
     int mode;        /* RRTO_MATH_* */
     int n_noise;     /* noise3D evaluation counter (diagnostic) */
     int n_dens;      /* density calls past the radial gate (diagnostic) */
+    /* hard-gate log of this ray (rrto_render_gates): 0 off, 1 record every decision, 2 replay recorded ones */
+    int gate_mode, gate_n, gate_cap, gate_overflow;
+    uint8_t* gate_log;
 } ctx_t;
+
+/* The path's hard gates -- `base < 0.001f` (densities.h:85), `d_disk > 0.001f`, `d_cloud > 0.001f`
+ * (raymarcher.cu:71,76,91) and the bloom threshold (post_processing.h:29) -- are the only places where a
+ * 1-ulp difference between two math libraries turns into a finite jump of the pixel.  In replay mode the
+ * decision recorded by another render of the same ray is taken instead of the comparison's, which makes the
+ * two renders comparable sample by sample (tests/test_gate_accounting.py). */
+static inline int gate(ctx_t* c, int decision) {
+    if (c->gate_mode == 0) return decision;
+    if (c->gate_n >= c->gate_cap) { c->gate_overflow = 1; return decision; }
+    if (c->gate_mode == 1) { c->gate_log[c->gate_n++] = (uint8_t)(decision != 0); return decision; }
+    return c->gate_log[c->gate_n++];
+}
+/* same for a small integer (two log bytes): the sky sampler's texel index and quantised filter weight */
+static inline int gate_int(ctx_t* c, int v) {
+    if (!c || c->gate_mode == 0) return v;
+    if (c->gate_n + 2 > c->gate_cap) { c->gate_overflow = 1; return v; }
+    if (c->gate_mode == 1) {
+        c->gate_log[c->gate_n++] = (uint8_t)(v & 255);
+        c->gate_log[c->gate_n++] = (uint8_t)((v >> 8) & 255);
+        return v;
+    }
+    int lo = c->gate_log[c->gate_n++], hi = c->gate_log[c->gate_n++];
+    return (int)(int16_t)(lo | (hi << 8));
+}
 
 static inline float m_pow(const ctx_t* c, float x, float y) { return c->mode ? rrt_powf(x, y) : powf(x, y); }
 static inline float m_exp(const ctx_t* c, float x) { return c->mode ? rrt_expf(x) : expf(x); }
@@ -232,7 +259,7 @@ static inline float dust_density(ctx_t* c, f3 p, float time) {
 
     float base = vertical_profile * edge_falloff * inner_taper;
 
-    if (base < 0.001f) return 0.0f;
+    if (gate(c, base < 0.001f)) return 0.0f;
 
     float phi = m_atan2(c, p.z, p.x);
     float omega = 1.0f * m_pow(c, ISCO_RADIUS / r, 1.5f);
@@ -272,14 +299,15 @@ static inline float dust_density(ctx_t* c, f3 p, float time) {
 }
 
 /* ---- radiative transfer of one in-zone sample: raymarcher.cu:71-116 ---- */
-static inline int rt_sample(const ctx_t* c, float d_disk, float d_cloud, f3 rel_p, float r, f3 vel, float current_h,
+static inline int rt_sample(ctx_t* c, float d_disk, float d_cloud, f3 rel_p, float r, f3 vel, float current_h,
                             float spin, float* intensity_r, float* intensity_g, float* intensity_b,
                             float* transmittance) {
-    if (d_disk > 0.001f || d_cloud > 0.001f) {
+    const int disk_on = gate(c, d_disk > 0.001f), cloud_on = gate(c, d_cloud > 0.001f);
+    if (disk_on || cloud_on) {
         f3 step_emit = mk3(0, 0, 0);
         float step_opacity = 0;
 
-        if (d_disk > 0.001f) {
+        if (disk_on) {
             float g = redshift_factor(c, rel_p, vel, spin);
             float T = disk_temperature(c, r);
             float T_norm = m_pow(c, T / DISK_TEMP_REF, 0.5f);
@@ -293,7 +321,7 @@ static inline int rt_sample(const ctx_t* c, float d_disk, float d_cloud, f3 rel_
             step_opacity += d_disk * DISK_OPACITY;
         }
 
-        if (d_cloud > 0.001f) {
+        if (cloud_on) {
             float g = redshift_factor(c, rel_p, vel, spin);
             float lighting = 0.5f + 3.0f * m_pow(c, ISCO_RADIUS / fmaxf(r, ISCO_RADIUS), 1.2f);
             float cloud_I = d_cloud * CLOUD_LUMINOSITY * lighting;
@@ -351,16 +379,23 @@ static inline f3 bloom_contribution(f3 color, float threshold) {
  */
 static inline int wrapi(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
 static inline int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
-static inline void sky_fetch(const uint8_t* sky, int sw, int sh, int frac_bits,
-                             float tx, float ty, float out[4]) {
+static inline void sky_fetch_g(ctx_t* c, const uint8_t* sky, int sw, int sh, int frac_bits,
+                               float tx, float ty, float out[4]) {
     float xb = tx * (float)sw - 0.5f;
     float yb = ty * (float)sh - 0.5f;
     float fi = floorf(xb), fj = floorf(yb);
     float a = xb - fi, b = yb - fj;
     if (frac_bits > 0) {
+        /* the quantised weights (and with them the texel pair) are step functions of the direction: the fifth
+         * "gate" of the path, logged / imposed like the others when a gate log is active */
         float q = (float)(1 << frac_bits);
-        a = floorf(a * q + 0.5f) / q;
-        b = floorf(b * q + 0.5f) / q;
+        float qa = floorf(a * q + 0.5f), qb = floorf(b * q + 0.5f);
+        if (c && c->gate_mode) {
+            fi = (float)gate_int(c, (int)fi); fj = (float)gate_int(c, (int)fj);
+            qa = (float)gate_int(c, (int)qa); qb = (float)gate_int(c, (int)qb);
+        }
+        a = qa / q;
+        b = qb / q;
     }
     int i0 = wrapi((int)fi, sw), i1 = wrapi((int)fi + 1, sw);
     int j0 = clampi((int)fj, 0, sh - 1), j1 = clampi((int)fj + 1, 0, sh - 1);
@@ -378,14 +413,18 @@ static inline void sky_fetch(const uint8_t* sky, int sw, int sh, int frac_bits,
     }
 }
 
+static inline void sky_fetch(const uint8_t* sky, int sw, int sh, int frac_bits, float tx, float ty, float out[4]) {
+    sky_fetch_g(0, sky, sw, sh, frac_bits, tx, ty, out);
+}
+
 /* raymarcher.cu:134-140 */
-static inline void sample_sky(const ctx_t* c, f3 dir, float off, const uint8_t* sky, int sw, int sh,
+static inline void sample_sky(ctx_t* c, f3 dir, float off, const uint8_t* sky, int sw, int sh,
                               int frac_bits, float out[4]) {
     float phi = m_atan2(c, dir.z, dir.x) + off;
     float theta = m_asin(c, dir.y);
     float tx = 0.5f + phi / (2.0f * PI);
     float ty = 0.5f - theta / PI;
-    sky_fetch(sky, sw, sh, frac_bits, tx, ty, out);
+    sky_fetch_g(c, sky, sw, sh, frac_bits, tx, ty, out);
 }
 
 /* ---- raymarcher.cu:15-174, one pixel ---- */
@@ -398,10 +437,20 @@ typedef struct {
     float rad[4];
 } pixel_out;
 
+static void trace_pixel_g(const rrto_camera* cam, const rrto_effects* fx, const rrto_params* prm,
+                          float time, int width, int height, int x, int y,
+                          const uint8_t* sky, int sw, int sh, pixel_out* o,
+                          int gate_mode, uint8_t* gate_log, int gate_cap, int* gate_n);
 static void trace_pixel(const rrto_camera* cam, const rrto_effects* fx, const rrto_params* prm,
                         float time, int width, int height, int x, int y,
                         const uint8_t* sky, int sw, int sh, pixel_out* o) {
-    ctx_t c = {prm->math_mode, 0, 0};
+    trace_pixel_g(cam, fx, prm, time, width, height, x, y, sky, sw, sh, o, 0, 0, 0, 0);
+}
+static void trace_pixel_g(const rrto_camera* cam, const rrto_effects* fx, const rrto_params* prm,
+                          float time, int width, int height, int x, int y,
+                          const uint8_t* sky, int sw, int sh, pixel_out* o,
+                          int gate_mode, uint8_t* gate_log, int gate_cap, int* gate_n) {
+    ctx_t c = {prm->math_mode, 0, 0, gate_mode, 0, gate_cap, 0, gate_log};
     const float spin = prm->spin;
 
     float uvx = (float)x / width;
@@ -483,7 +532,9 @@ static void trace_pixel(const rrto_camera* cam, const rrto_effects* fx, const rr
     final_hdr.z = intensity_b + bg_color.z * transmittance;
 
     if (fx->use_bloom) {
-        f3 bloom = bloom_contribution(final_hdr, fx->bloom_threshold);
+        /* get_bloom_contribution (post_processing.h:27-31), its threshold test routed through the gate log */
+        float brightness = dot3(final_hdr, mk3(0.2126f, 0.7152f, 0.0722f));
+        f3 bloom = gate(&c, brightness > fx->bloom_threshold) ? final_hdr : mk3(0, 0, 0);
         final_hdr = add3(final_hdr, mul3(bloom, fx->bloom_intensity));
     }
     if (fx->use_vignette) {
@@ -507,6 +558,7 @@ static void trace_pixel(const rrto_camera* cam, const rrto_effects* fx, const rr
     o->n_dens = c.n_dens;
     o->p = p; o->v = vel;
     o->rad[0] = intensity_r; o->rad[1] = intensity_g; o->rad[2] = intensity_b; o->rad[3] = transmittance;
+    if (gate_n) *gate_n = c.gate_overflow ? -1 : c.gate_n;
 }
 
 int rrto_render(const rrto_camera* cam, const rrto_effects* fx, const rrto_params* prm,
@@ -514,7 +566,18 @@ int rrto_render(const rrto_camera* cam, const rrto_effects* fx, const rrto_param
                 int x0, int y0, int x1, int y1, int sx, int sy,
                 const uint8_t* sky, int sw, int sh,
                 uint8_t* rgba8, float* ldr, float* hdr, const rrto_diag* diag, int n_threads) {
+    return rrto_render_gates(cam, fx, prm, time, width, height, x0, y0, x1, y1, sx, sy, sky, sw, sh, rgba8, ldr, hdr, diag,
+                             n_threads, 0, 0, 0, 0);
+}
+
+int rrto_render_gates(const rrto_camera* cam, const rrto_effects* fx, const rrto_params* prm,
+                      float time, int width, int height,
+                      int x0, int y0, int x1, int y1, int sx, int sy,
+                      const uint8_t* sky, int sw, int sh,
+                      uint8_t* rgba8, float* ldr, float* hdr, const rrto_diag* diag, int n_threads,
+                      int gate_mode, uint8_t* gate_log, int gate_cap, int32_t* gate_count) {
     if (!cam || !fx || !prm || !sky || width <= 0 || height <= 0 || sw <= 0 || sh <= 0) return -1;
+    if (gate_mode < 0 || gate_mode > 2 || (gate_mode && (!gate_log || !gate_count || gate_cap <= 0))) return -1;
     if (x0 < 0 || y0 < 0 || x1 > width || y1 > height || sx <= 0 || sy <= 0) return -1;
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
@@ -522,14 +585,24 @@ int rrto_render(const rrto_camera* cam, const rrto_effects* fx, const rrto_param
     (void)n_threads;
 #endif
     int ny = (y1 - y0 + sy - 1) / sy;
+    const int nxs = (x1 - x0 + sx - 1) / sx;            /* gate logs are indexed by sample: jy*nxs + jx */
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
     for (int jy = 0; jy < ny; ++jy) {
         int y = y0 + jy * sy;
         for (int x = x0; x < x1; x += sx) {
+            const size_t gi = (size_t)jy * nxs + (size_t)((x - x0) / sx);
             pixel_out o;
-            trace_pixel(cam, fx, prm, time, width, height, x, y, sky, sw, sh, &o);
             size_t oi = (size_t)(height - 1 - y) * width + x;   /* raymarcher.cu:168 */
             size_t di = (size_t)y * width + x;
+            if (gate_mode) {
+                int n = 0;
+                trace_pixel_g(cam, fx, prm, time, width, height, x, y, sky, sw, sh, &o, gate_mode,
+                              gate_log + gi * (size_t)gate_cap, gate_cap, &n);
+                if (gate_mode == 1) gate_count[gi] = n;            /* -1: the log overflowed */
+                else if (n != gate_count[gi]) gate_count[gi] = -2;  /* replay saw a different number of gates */
+            } else {
+                trace_pixel(cam, fx, prm, time, width, height, x, y, sky, sw, sh, &o);
+            }
             if (rgba8) memcpy(rgba8 + 4 * oi, o.rgba, 4);
             if (ldr) { ldr[4 * oi] = o.ldr[0]; ldr[4 * oi + 1] = o.ldr[1]; ldr[4 * oi + 2] = o.ldr[2]; ldr[4 * oi + 3] = 1.0f; }
             if (hdr) { hdr[4 * oi] = o.hdr[0]; hdr[4 * oi + 1] = o.hdr[1]; hdr[4 * oi + 2] = o.hdr[2]; hdr[4 * oi + 3] = 1.0f; }
@@ -576,8 +649,8 @@ static inline f3 ld3(const float* a, int i) { return mk3(a[3 * i], a[3 * i + 1],
 static inline void st3(float* a, int i, f3 v) { a[3 * i] = v.x; a[3 * i + 1] = v.y; a[3 * i + 2] = v.z; }
 
 void rrto_hash31(int n, const float* p, float* out) { for (int i = 0; i < n; ++i) out[i] = hash31(ld3(p, i)); }
-void rrto_noise3d(int n, const float* p, float* out) { ctx_t c = {0, 0, 0}; for (int i = 0; i < n; ++i) out[i] = noise3d(&c, ld3(p, i)); }
-void rrto_fbm(int n, const float* p, int oct, float* out) { ctx_t c = {0, 0, 0}; for (int i = 0; i < n; ++i) out[i] = fbm(&c, ld3(p, i), oct); }
+void rrto_noise3d(int n, const float* p, float* out) { ctx_t c = {0, 0, 0, 0, 0, 0, 0, 0}; for (int i = 0; i < n; ++i) out[i] = noise3d(&c, ld3(p, i)); }
+void rrto_fbm(int n, const float* p, int oct, float* out) { ctx_t c = {0, 0, 0, 0, 0, 0, 0, 0}; for (int i = 0; i < n; ++i) out[i] = fbm(&c, ld3(p, i), oct); }
 void rrto_geodesic_acc(int n, const float* p, const float* v, float spin, float* out) {
     for (int i = 0; i < n; ++i) st3(out, i, geodesic_acc(ld3(p, i), ld3(v, i), spin));
 }
@@ -585,16 +658,16 @@ void rrto_rk4(int n, float* p, float* v, const float* h, float spin) {
     for (int i = 0; i < n; ++i) { f3 pp = ld3(p, i), vv = ld3(v, i); integrate_rk4(&pp, &vv, h[i], spin); st3(p, i, pp); st3(v, i, vv); }
 }
 void rrto_redshift(int n, const float* p, const float* vel, float spin, int mode, float* out) {
-    ctx_t c = {mode, 0, 0}; for (int i = 0; i < n; ++i) out[i] = redshift_factor(&c, ld3(p, i), ld3(vel, i), spin);
+    ctx_t c = {mode, 0, 0, 0, 0, 0, 0, 0}; for (int i = 0; i < n; ++i) out[i] = redshift_factor(&c, ld3(p, i), ld3(vel, i), spin);
 }
 void rrto_disk_temperature(int n, const float* r, int mode, float* out) {
-    ctx_t c = {mode, 0, 0}; for (int i = 0; i < n; ++i) out[i] = disk_temperature(&c, r[i]);
+    ctx_t c = {mode, 0, 0, 0, 0, 0, 0, 0}; for (int i = 0; i < n; ++i) out[i] = disk_temperature(&c, r[i]);
 }
 void rrto_accretion_density(int n, const float* p, float time, int mode, float* out) {
-    ctx_t c = {mode, 0, 0}; for (int i = 0; i < n; ++i) out[i] = accretion_density(&c, ld3(p, i), time);
+    ctx_t c = {mode, 0, 0, 0, 0, 0, 0, 0}; for (int i = 0; i < n; ++i) out[i] = accretion_density(&c, ld3(p, i), time);
 }
 void rrto_dust_density(int n, const float* p, float time, int mode, float* out) {
-    ctx_t c = {mode, 0, 0}; for (int i = 0; i < n; ++i) out[i] = dust_density(&c, ld3(p, i), time);
+    ctx_t c = {mode, 0, 0, 0, 0, 0, 0, 0}; for (int i = 0; i < n; ++i) out[i] = dust_density(&c, ld3(p, i), time);
 }
 void rrto_smoothstep(int n, const float* e0, const float* e1, const float* x, float* out) {
     for (int i = 0; i < n; ++i) out[i] = smoothstepf(e0[i], e1[i], x[i]);
@@ -615,12 +688,12 @@ void rrto_sky_fetch(const uint8_t* sky, int sw, int sh, int frac_bits, float tx,
 }
 void rrto_sky_sample(int n, const float* dir, float off, const uint8_t* sky, int sw, int sh,
                      int frac_bits, int mode, float* out) {
-    ctx_t c = {mode, 0, 0}; for (int i = 0; i < n; ++i) sample_sky(&c, ld3(dir, i), off, sky, sw, sh, frac_bits, out + 4 * i);
+    ctx_t c = {mode, 0, 0, 0, 0, 0, 0, 0}; for (int i = 0; i < n; ++i) sample_sky(&c, ld3(dir, i), off, sky, sw, sh, frac_bits, out + 4 * i);
 }
 /* one radiative-transfer sample per element: rad (r,g,b,T) is updated in place */
 void rrto_rt_sample(int n, const float* d_disk, const float* d_cloud, const float* p, const float* vel,
                     const float* h, float spin, int mode, float* rad) {
-    ctx_t c = {mode, 0, 0};
+    ctx_t c = {mode, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < n; ++i) {
         f3 rp = ld3(p, i);
         rt_sample(&c, d_disk[i], d_cloud[i], rp, length3(rp), ld3(vel, i), h[i], spin,
@@ -629,7 +702,7 @@ void rrto_rt_sample(int n, const float* d_disk, const float* d_cloud, const floa
 }
 
 void rrto_math(int fn, int mode, int n, const float* a, const float* b, float* out) {
-    ctx_t c = {mode, 0, 0};
+    ctx_t c = {mode, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < n; ++i) {
         switch (fn) {
             case 0: out[i] = m_exp(&c, a[i]); break;

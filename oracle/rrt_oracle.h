@@ -120,6 +120,23 @@ int rrto_render(const rrto_camera* cam, const rrto_effects* fx, const rrto_param
                 uint8_t* rgba8, float* ldr, float* hdr, const rrto_diag* diag,
                 int n_threads);
 
+/*
+ * The same render with the ray's hard-gate decisions logged or imposed (see `gate` in rrt_oracle.c):
+ *   gate_mode 1: every decision of the s-th rendered pixel (s = jy*nx + jx over the strided sample grid of the
+ *                rectangle, row-major, top-down) is appended to gate_log[s*gate_cap ...], their number goes to
+ *                gate_count[s] (-1 if more than gate_cap);
+ *   gate_mode 2: the decisions are READ from gate_log instead of being evaluated (gate_count[..] becomes -2 if
+ *                the ray asks for a different number of decisions than were recorded);
+ *   gate_mode 0: plain rrto_render.
+ * Used to separate gate flips from arithmetic differences when two math libraries are compared.
+ */
+int rrto_render_gates(const rrto_camera* cam, const rrto_effects* fx, const rrto_params* prm,
+                      float time, int width, int height,
+                      int x0, int y0, int x1, int y1, int sx, int sy,
+                      const uint8_t* sky_rgba8, int sky_w, int sky_h,
+                      uint8_t* rgba8, float* ldr, float* hdr, const rrto_diag* diag, int n_threads,
+                      int gate_mode, uint8_t* gate_log, int gate_cap, int32_t* gate_count);
+
 int rrto_max_threads(void);
 
 #ifdef __cplusplus
