@@ -246,6 +246,8 @@ int rrt_unit_media_lut(int n, const float* d_p, float time, int table, float* d_
  * [0] receives the number of mismatching cases, [1..3] one failing case. */
 int rrt_selfcheck_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* stream);
 int rrt_selfcheck_div(unsigned long long n_cases, uint32_t seed, unsigned long long* d_counters, void* stream);
+/* the media code's scaling-free division (csrc/rrt_device.h: rrt_div_tame) on random tame operand pairs */
+int rrt_selfcheck_div_tame(unsigned long long n_cases, uint32_t seed, unsigned long long* d_counters, void* stream);
 
 /* ---- host-side camera helpers (host C++ in the reference too) ---- */
 /* CameraController::getCUDAStateFrom, src/main.cpp:141-167 (degrees; note its 3.14159f) */

@@ -20,6 +20,30 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+/*
+ * Correctly rounded a / b without hipcc's range scaling: v_rcp_f32 (1 ulp), one Newton refinement, then the
+ * Markstein residual corrections -- the FMA core of LLVM's own f32 division, which is what `/` compiles to minus
+ * v_div_scale / v_div_fmas / v_div_fixup.  Bit-identical to IEEE `/` whenever those would have been no-ops:
+ * b normal with 2^-60 <= |b| <= 2^60, and a == 0 or 2^-60 <= |a / b| <= 2^60 ("tame" operands; checked on 2^33
+ * random tame pairs, tests/test_gpu_units.py).  10 issue slots instead of ~20.  Used only where the operand
+ * ranges are known by construction -- each use says why.
+ */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RRT_NO_LEAN)     /* -DRRT_NO_LEAN: A/B builds with hipcc's IEEE forms everywhere */
+__device__ __forceinline__ float rrt_div_core(float a, float b, float seed) {
+    float e = __builtin_fmaf(-b, seed, 1.0f);
+    float y = __builtin_fmaf(e, seed, seed);
+    float q = a * y;
+    float r = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, y, q);
+}
+__device__ __forceinline__ float rrt_div_tame(float a, float b) { return rrt_div_core(a, b, __builtin_amdgcn_rcpf(b)); }
+#define RRT_MATH_TAME_DIV(a, b) rrt_div_tame((a), (b))
+#else
+__host__ __device__ static inline float rrt_div_tame(float a, float b) { return a / b; }   /* host pass: never executed */
+#endif
+
 #include "rrt_math.h"
 
 #define RRT_DEV __device__ __forceinline__
@@ -64,6 +88,8 @@ RRT_DEV float smoothstep(float e0, float e1, float x) {                         
     float t = fmin2(fmax2((x - e0) / (e1 - e0), 0.0f), 1.0f);
     return t * t * (3.0f - 2.0f * t);
 }
+
+template <bool LEAN> RRT_DEV float smoothstep_t(float e0, float e1, float x);      /* below: needs rrt_div_tame */
 
 /* fmodf(x, 1.0f) for finite x: exact, differs from libm only in the sign of a zero. */
 RRT_DEV float fmod1(float x) { return x - __builtin_truncf(x); }
@@ -207,6 +233,29 @@ RRT_DEV float div_seeded(float a, float b, float seed) {
     return __builtin_fmaf(r, y, q);
 }
 
+/* sqrtf for operands in [2^-40, 2^64) (every float in that range checked against v_sqrt-based sqrtf) */
+#ifdef RRT_NO_LEAN
+RRT_DEV float sqrt_tame(float x) { return sqrtf(x); }
+#else
+RRT_DEV float sqrt_tame(float x) { float r, y; sqrt_rsq(x, r, y); return r; }
+#endif
+
+/* smoothstep (math_utils.h:45-48) with literal edges: the divisor e1 - e0 is a constant of magnitude 0.4 .. 5 and
+ * the dividend a bounded difference, so the division is tame (a zero dividend gives the IEEE zero) */
+template <bool LEAN>
+RRT_DEV float smoothstep_t(float e0, float e1, float x) {
+    const float q = LEAN ? rrt_div_tame(x - e0, e1 - e0) : (x - e0) / (e1 - e0);
+    const float t = fmin2(fmax2(q, 0.0f), 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+/* Division / square root of the media code: LEAN = the bare cores above on operands that are tame by
+ * construction (the render kernels), otherwise hipcc's IEEE forms (unit kernels on arbitrary points). */
+template <bool LEAN> struct Ar {
+    static RRT_DEV float div(float a, float b) { return LEAN ? rrt_div_tame(a, b) : a / b; }
+    static RRT_DEV float sqrt(float x) { return LEAN ? sqrt_tame(x) : sqrtf(x); }
+};
+
 /*
  * getGeodesicAcc, geodesics.h:30-45, with SPIN_AXIS = (0,1,0), EVENT_HORIZON = 2:
  *   radial = (-1.5f*2.0f * L2 / (r2*r2*r)) * p        (-1.5f*2.0f folds to -3.0f)
@@ -343,9 +392,27 @@ RRT_DEV void integrate_rk4_fast(v3& p, v3& v, float h, float hh, float h6, float
     p = axpy(kp_sum, h6, p0);
 }
 
-/* calculateRedshiftFactor, geodesics.h:11-25; `r` = length(p) is passed in by callers that already hold it */
+/* calculateRedshiftFactor, geodesics.h:11-25; `r` = length(p) is passed in by callers that already hold it.
+ * LEAN (render kernels; called only for samples with a density > 0.001, i.e. cylindrical radius in [10, 25] and
+ * r in [10, 30)): the tame operands are r (2/r, sqrt(1 - 2/r) with argument in [0.8, 0.94]), r^1.5 + a in
+ * [30, 170] for |a| <= 1, the cylindrical radius `mag` in [10, 25] of the gas direction, and 1 - v^2 in
+ * [0.998, 1].  The Doppler denominator gamma*(1 - v cos) is NOT bounded away from zero (the ray "velocity" is not
+ * normalised) and keeps the IEEE division, as does everything when |a| > 1. */
+template <bool LEAN>
 RRT_DEV float redshift_factor_r(v3 p, float r, v3 ray_vel, float spin) {
     if (r < kEventHorizon * 1.01f) return 0.0f;
+    const float gx = -p.z, gz = p.x;
+    const float m2 = gx * gx + 0.0f * 0.0f + gz * gz;                              /* length(make_float3(-z, 0, x))^2 */
+    if (LEAN && __builtin_expect(fabsf(spin) <= 1.0f && r >= 9.0f && r < 64.0f && m2 >= 1.0f && m2 < 4096.0f, 1)) {
+        const float g_gravity = sqrt_tame(1.0f - rrt_div_tame(kEventHorizon, r));
+        const float v_mag = rrt_div_tame(1.0f, r * sqrt_tame(r) + spin);          /* rrt_powf(r, 1.5f) == r * sqrt(r) */
+        const float mag = sqrt_tame(m2);                                           /* >= 1: normalize() divides (math_utils.h:23-27) */
+        const v3 gas_dir = mk(rrt_div_tame(gx, mag), 0.0f, rrt_div_tame(gz, mag)); /* 0 / mag == +0 */
+        const float cos_theta = dot(ray_vel, gas_dir);
+        const float gamma = rrt_div_tame(1.0f, sqrt_tame(1.0f - v_mag * v_mag));
+        const float g_doppler = 1.0f / (gamma * (1.0f - v_mag * cos_theta));
+        return g_gravity * g_doppler;
+    }
     float g_gravity = sqrtf(1.0f - kEventHorizon / r);
     float v_mag = 1.0f / (rrt_powf(r, 1.5f) + spin);
     v3 gas_dir = normalize(mk(-p.z, 0.f, p.x));
@@ -354,13 +421,16 @@ RRT_DEV float redshift_factor_r(v3 p, float r, v3 ray_vel, float spin) {
     float g_doppler = 1.0f / (gamma * (1.0f - v_mag * cos_theta));
     return g_gravity * g_doppler;
 }
-RRT_DEV float redshift_factor(v3 p, v3 ray_vel, float spin) { return redshift_factor_r(p, length(p), ray_vel, spin); }
+RRT_DEV float redshift_factor(v3 p, v3 ray_vel, float spin) { return redshift_factor_r<false>(p, length(p), ray_vel, spin); }
 
-/* getDiskTemperature, densities.h:12-15 */
-RRT_DEV float disk_temperature(float r) {
+/* getDiskTemperature, densities.h:12-15 (LEAN: r in [10, 64) -- the callers' density gate) */
+template <bool LEAN>
+RRT_DEV float disk_temperature_t(float r) {
     if (r < kIsco) return 0.0f;
-    return kDiskTempRef * rrt_powf(r / kIsco, -0.75f);
+    const float x = (LEAN && r < 64.0f) ? rrt_div_tame(r, kIsco) : r / kIsco;
+    return kDiskTempRef * rrt_powf(x, -0.75f);
 }
+RRT_DEV float disk_temperature(float r) { return disk_temperature_t<false>(r); }
 
 /* one noise3D evaluation, from the table when the wave-uniform switch says so */
 template <bool LUT>
@@ -392,18 +462,25 @@ constexpr int kLutRidgeOctaves = 3;    /* dust ridge sum: octaves 0..2 */
  */
 template <bool EARLY_OUT, bool LUT>
 RRT_DEV float accretion_density(v3 p, float time, const NoiseLut& L, unsigned* oob) {
-    const float rc = sqrtf(p.x * p.x + 0.0f * 0.0f + p.z * p.z);
+    /* The render kernels (EARLY_OUT) call this only inside the disk zone, |y| < 4 and r < 30 (raymarcher.cu:57), so
+     * every division / square root below has tame operands once the radial gate has passed: rc in [10, 25],
+     * q = 10/rc in [0.4, 1], thick in [0.5, 0.8], y*y < 16 (a y*y too small for the bare division to be exact,
+     * < 2^-100, feeds exp(-0) = 1 either way). */
+    constexpr bool LEAN = EARLY_OUT;
+    const float rc2 = p.x * p.x + 0.0f * 0.0f + p.z * p.z;
+    if (LEAN && !(rc2 >= 1.0f)) return 0.0f;                      /* rc < 1 < ISCO; keeps sqrt_tame in range */
+    const float rc = Ar<LEAN>::sqrt(rc2);
     if (rc < kIsco || rc > kDiskOut) return 0.0f;
 
     float rim = 1.0f;                                   /* taper of the outer 15 % (:25-30) */
     const float rim_from = kDiskOut * 0.85f;
     if (rc > rim_from) {
-        rim = 1.0f - (rc - rim_from) / (kDiskOut - rim_from);
+        rim = 1.0f - Ar<LEAN>::div(rc - rim_from, kDiskOut - rim_from);
         rim *= rim;
     }
-    const float q = kIsco / rc;
-    const float thick = kDiskH * rrt_powf(q, 0.5f);
-    const float slab = rrt_expf(-(p.y * p.y) / (2.0f * thick * thick + 1e-7f));
+    const float q = Ar<LEAN>::div(kIsco, rc);
+    const float thick = kDiskH * (LEAN ? sqrt_tame(q) : rrt_powf(q, 0.5f));
+    const float slab = rrt_expf(Ar<LEAN>::div(-(p.y * p.y), 2.0f * thick * thick + 1e-7f));
     const float fall = rrt_powf(q, 0.4f);
     const float envelope = slab * fall * rim;
 
@@ -416,7 +493,7 @@ RRT_DEV float accretion_density(v3 p, float time, const NoiseLut& L, unsigned* o
     if (EARLY_OUT && envelope * (0.02f + 5.0f * 6.0f) <= 0.001f) return 0.0f;
 
     const float azimuth = rrt_atan2f(p.z, p.x);
-    const float kepler = 3.5f * rrt_powf(q, 1.5f);
+    const float kepler = 3.5f * (LEAN ? q * sqrt_tame(q) : rrt_powf(q, 1.5f));
     const float turned = azimuth - time * kepler;
     float sn, cs;
     rrt_sincosf(turned, &sn, &cs);
@@ -447,22 +524,25 @@ RRT_DEV float accretion_density(v3 p, float time, const NoiseLut& L, unsigned* o
     return envelope * (0.02f + 5.0f * streak);
 }
 
-/* getDustCloudDensity, densities.h:69-132 */
-template <bool LUT>
+/* getDustCloudDensity, densities.h:69-132.  LEAN (the render kernels, which call it only inside the cloud zone
+ * |y| < 0.75, r < 25: raymarcher.cu:58): the same tame-operand argument as in accretion_density. */
+template <bool LUT, bool LEAN = true>
 RRT_DEV float dust_density(v3 p, float time, const NoiseLut& L, unsigned* oob) {
-    const float rc = sqrtf(p.x * p.x + 0.0f * 0.0f + p.z * p.z);
+    const float rc2 = p.x * p.x + 0.0f * 0.0f + p.z * p.z;
+    if (LEAN && !(rc2 >= 1.0f)) return 0.0f;
+    const float rc = Ar<LEAN>::sqrt(rc2);
     if (rc < kIsco || rc > kDiskOut) return 0.0f;
 
-    const float outer = smoothstep(kDiskOut, kDiskOut * 0.8f, rc);
-    const float inner = smoothstep(kIsco, kIsco + 5.0f, rc);
-    const float q = kIsco / rc;
+    const float outer = smoothstep_t<LEAN>(kDiskOut, kDiskOut * 0.8f, rc);
+    const float inner = smoothstep_t<LEAN>(kIsco, kIsco + 5.0f, rc);
+    const float q = Ar<LEAN>::div(kIsco, rc);
     const float thick = kCloudH * 0.5f * rrt_powf(q, 0.2f);
-    const float slab = rrt_expf(-(p.y * p.y) / (2.0f * thick * thick + 1e-7f));
+    const float slab = rrt_expf(Ar<LEAN>::div(-(p.y * p.y), 2.0f * thick * thick + 1e-7f));
     const float envelope = slab * outer * inner;
     if (envelope < 0.001f) return 0.0f;                 /* densities.h:85 */
 
     const float azimuth = rrt_atan2f(p.z, p.x);
-    const float kepler = rrt_powf(q, 1.5f);             /* 1.0f * pow(...) */
+    const float kepler = LEAN ? q * sqrt_tame(q) : rrt_powf(q, 1.5f);     /* 1.0f * pow(...) */
     const float sheared = azimuth - time * kepler;
 
     const v3 sc = mk(rc * 0.8f, p.y * 15.0f, sheared * 10.0f);     /* `coords`, :93 */
@@ -519,7 +599,7 @@ RRT_DEV float dust_density(v3 p, float time, const NoiseLut& L, unsigned* oob) {
         amp *= 0.5f;
         freq *= 2.1f;
     }
-    float strands = smoothstep(0.4f, 0.8f, n * 0.55f);
+    float strands = smoothstep_t<LEAN>(0.4f, 0.8f, n * 0.55f);
     strands = rrt_powf(strands, 4.0f);
     const v3 dc = mul(fc, 4.0f);
     const float detail = fbm2_sel<LUT>(mk(dc.x + 0.0f, dc.y + time * 0.5f, dc.z + 0.0f), L, from_table & 256u, false, oob);
@@ -537,13 +617,16 @@ RRT_DEV bool sample_emission(float d_disk, float d_cloud, v3 rel_p, float r, v3 
                              float& ex, float& ey, float& ez, float& step_trans) {
     const bool disk_on = d_disk > 0.001f, dust_on = d_cloud > 0.001f;
     if (!(disk_on || dust_on)) return false;
+    /* a density above the gate means the cylindrical radius is in [10, 25] and the sample inside a zone, so
+     * r in [10, 30): the tame range of the lean divisions / square roots (their guards fall back otherwise) */
     ex = 0.f; ey = 0.f; ez = 0.f;
     float opacity = 0.f;
-    const float g = redshift_factor_r(rel_p, r, vel, spin);
+    const float g = redshift_factor_r<true>(rel_p, r, vel, spin);
     if (disk_on) {
-        float T = disk_temperature(r);
-        float tn = T / kDiskTempRef;
-        float T_norm = rrt_powf(tn, 0.5f);
+        float T = disk_temperature_t<true>(r);
+        const bool tame = T >= 1.0f;                             /* T in [6.6e6, 1.5e7] for r in [10, 30) */
+        float tn = tame ? rrt_div_tame(T, kDiskTempRef) : T / kDiskTempRef;
+        float T_norm = tame ? sqrt_tame(tn) : rrt_powf(tn, 0.5f);
         float bol_I = rrt_powf(g, 4.0f) * T_norm * d_disk * kDiskLum;
         float color_t = g * rrt_powf(tn, 0.4f) * 2.5f;
         ex += bol_I;                                             /* 1.0f * bol_I */
@@ -552,7 +635,8 @@ RRT_DEV bool sample_emission(float d_disk, float d_cloud, v3 rel_p, float r, v3 
         opacity += d_disk * kDiskOpacity;
     }
     if (dust_on) {
-        float lighting = 0.5f + 3.0f * rrt_powf(kIsco / fmax2(r, kIsco), 1.2f);
+        const float rr = fmax2(r, kIsco);
+        float lighting = 0.5f + 3.0f * rrt_powf(rr < 64.0f ? rrt_div_tame(kIsco, rr) : kIsco / rr, 1.2f);
         float cloud_I = d_cloud * kCloudLum * lighting;
         float shift = smoothstep(0.7f, 1.3f, g);
         ex += 0.60f * cloud_I * lerp(1.2f, 0.8f, shift);

@@ -759,11 +759,11 @@ __global__ void k_accretion(int n, const float* p, float time, float* out) {
 }
 __global__ void k_dust(int n, const float* p, float time, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = dust_density<false>(ld3(p, i), time, NoiseLut{}, nullptr);
+    if (i < n) out[i] = dust_density<false, false>(ld3(p, i), time, NoiseLut{}, nullptr);
 }
 __global__ void k_redshift(int n, const float* p, const float* vel, float spin, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = redshift_factor(ld3(p, i), ld3(vel, i), spin);
+    if (i < n) out[i] = redshift_factor(ld3(p, i), ld3(vel, i), spin);          /* the literal (IEEE-division) form */
 }
 __global__ void k_math(int fn, int n, const float* a, const float* b, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -883,6 +883,24 @@ __global__ void k_selfcheck_div(unsigned long long n, uint32_t seed, unsigned lo
         float w1 = num / d1, w2 = c / d2;
         if (rrt_f2u(q1) != rrt_f2u(w1)) { ++bad; counters[1] = rrt_f2u(num); counters[2] = rrt_f2u(d1); }
         if (rrt_f2u(q2) != rrt_f2u(w2)) { ++bad; counters[1] = rrt_f2u(c); counters[2] = rrt_f2u(d2); counters[3] = 2; }
+    }
+    if (bad) atomicAdd(counters, (unsigned long long)bad);
+}
+
+/* rrt_div_tame against IEEE `/` on `n` pseudo-random tame operand pairs: |b| in 2^[-40, 40), |a| in 2^[-20, 20) times
+ * |b| (so |a/b| in 2^[-20, 20)), random signs, plus a == 0 every 64th case. */
+__global__ void k_selfcheck_div_tame(unsigned long long n, uint32_t seed, unsigned long long* counters) {
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned bad = 0;
+    for (uint64_t k = idx; k < n; k += stride) {
+        uint32_t h1 = mix32((uint32_t)k * 2654435761u + seed), h2 = mix32(h1 ^ (uint32_t)(k >> 32) ^ 0x9e3779b9u);
+        uint32_t h3 = mix32(h2 + 0x85ebca6bu);
+        float b = rrt_u2f(((87u << 23) + (h1 % (80u << 23))) | (h3 & 0x80000000u));          /* +-2^[-40, 40) */
+        float ratio = rrt_u2f(((107u << 23) + (h2 % (40u << 23))) | ((h3 << 1) & 0x80000000u));  /* +-2^[-20, 20) */
+        float a = (k & 63) == 0 ? 0.0f : b * ratio;
+        float q = rrt_div_tame(a, b), w = a / b;
+        if (rrt_f2u(q) != rrt_f2u(w)) { ++bad; counters[1] = rrt_f2u(a); counters[2] = rrt_f2u(b); }
     }
     if (bad) atomicAdd(counters, (unsigned long long)bad);
 }
@@ -1489,6 +1507,12 @@ int rrt_unit_media_lut(int n, const float* p, float time, int table, float* out_
 int rrt_selfcheck_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* st) {
     if (!d_counters || lo_bits > hi_bits) return RRT_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(k_selfcheck_sqrt, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(st), lo_bits, hi_bits, d_counters);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+int rrt_selfcheck_div_tame(unsigned long long n, uint32_t seed, unsigned long long* d_counters, void* st) {
+    if (!d_counters) return RRT_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(k_selfcheck_div_tame, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(st), n, seed, d_counters);
     RRT_HIP(hipGetLastError());
     return RRT_OK;
 }

@@ -44,6 +44,14 @@ RRT_FN float rrt_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c)
 RRT_FN float rrt_sqrt(float x) { return __builtin_sqrtf(x); }
 RRT_FN float rrt_abs(float x) { return __builtin_fabsf(x); }
 
+/* Hook for the two divisions below whose operands are tame by construction (the denominator lies in [1.4, 3.5],
+ * the quotient in (-1, 1.1]): the gfx950 kernels substitute a bare reciprocal + Markstein sequence that gives the
+ * IEEE quotient bit for bit on such operands (csrc/rrt_device.h: rrt_div_tame) but skips hipcc's range scaling;
+ * every other translation unit (the CPU oracle) uses the plain `/`. */
+#ifndef RRT_MATH_TAME_DIV
+#define RRT_MATH_TAME_DIV(a, b) ((a) / (b))
+#endif
+
 #define RRT_LN2_HI 0.693359375f        /* 10 significant bits: k*LN2_HI is exact */
 #define RRT_LN2_LO (-2.12194440e-4f)   /* ln2 = LN2_HI + LN2_LO */
 #define RRT_LOG2E 1.44269504088896341f
@@ -91,7 +99,7 @@ RRT_FN float rrt_pow_pos(float x, float y) {
     float f = m - 1.0f;                              /* exact */
     float t = 2.0f + f;
     float t_lo = (2.0f - t) + f;                     /* exact rounding error of t */
-    float rt = 1.0f / t;
+    float rt = RRT_MATH_TAME_DIV(1.0f, t);             /* t in [1.70, 2.42] */
     float s = f * rt;
     float res = rrt_fma(-s, t, f);
     res = rrt_fma(-s, t_lo, res);
@@ -169,7 +177,7 @@ RRT_FN float rrt_atanf(float x) {
     float ax = rrt_abs(x);
     float y0, t;
     if (ax > 2.414213562373095f) { y0 = 1.5707963267948966f; t = -1.0f / ax; }
-    else if (ax > 0.4142135623730950f) { y0 = 0.7853981633974483f; t = (ax - 1.0f) / (ax + 1.0f); }
+    else if (ax > 0.4142135623730950f) { y0 = 0.7853981633974483f; t = RRT_MATH_TAME_DIV(ax - 1.0f, ax + 1.0f); }
     else { y0 = 0.0f; t = ax; }
     float z = t * t;
     float p = 8.05374449538e-2f;

@@ -271,6 +271,24 @@ def test_fast_divide_is_correctly_rounded_on_march_operands(g):
     assert int(cnt[0]) == 0, f"{int(cnt[0])} mismatches, e.g. {int(cnt[1]):#x} / {int(cnt[2]):#x}"
 
 
+def test_media_sqrt_and_divide_cores_are_correctly_rounded(g):
+    """The volumetric code's scaling-free sqrt / divide (rrt_device.h: sqrt_tame, rrt_div_tame) == the IEEE forms:
+    sqrt on EVERY float of [2^-40, 1) (the range above 1 is covered by the march's check), divide on 2^32 random
+    tame operand pairs."""
+    import ctypes as C
+    import torch
+    from relativisticraytracer_amd import _lib
+    cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
+    lo, hi = 0x3f800000 - (40 << 23), 0x3f800000
+    _lib.check(_lib.load().rrt_selfcheck_sqrt(lo, hi, C.c_void_p(cnt.data_ptr()), None), "selfcheck_sqrt")
+    torch.cuda.synchronize()
+    assert int(cnt[0]) == 0, f"sqrt: {int(cnt[0])} mismatches, e.g. bits {int(cnt[1]):#x}"
+    cnt.zero_()
+    _lib.check(_lib.load().rrt_selfcheck_div_tame(1 << 32, 777, C.c_void_p(cnt.data_ptr()), None), "selfcheck_div_tame")
+    torch.cuda.synchronize()
+    assert int(cnt[0]) == 0, f"div: {int(cnt[0])} mismatches, e.g. {int(cnt[1]):#x} / {int(cnt[2]):#x}"
+
+
 def test_unit_kernels_empty_and_bad_args(g):
     import torch
     from relativisticraytracer_amd import _lib
