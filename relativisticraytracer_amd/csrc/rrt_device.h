@@ -453,24 +453,45 @@ RRT_DEV float fbm2_sel(v3 p, const NoiseLut& L, bool t0, bool t1, unsigned* oob)
 }
 
 /* Highest octave of each noise call family that the tables cover (rrt_hip.hip sizes the boxes from these). */
-constexpr int kLutAccOctaves = 4;      /* accretion fbm(.,5): octaves 0..3 */
+#ifndef RRT_LUT_ACC_OCT
+#define RRT_LUT_ACC_OCT 4
+#endif
+constexpr int kLutAccOctaves = RRT_LUT_ACC_OCT;      /* accretion fbm(.,5): octaves 0..3 */
 constexpr int kLutRidgeOctaves = 3;    /* dust ridge sum: octaves 0..2 */
 
 /*
  * getAccretionDensity, densities.h:20-62.  EARLY_OUT=false, LUT=false is the literal function (unit
  * tests); the render kernels use EARLY_OUT=true (see below) and, with a noise table, LUT=true.
  */
+/* What both density functions derive from the sample position alone -- cylindrical radius and radial gate
+ * (densities.h:21-22, :70-71), q = ISCO/rc and its square root (:32, :41, :79, :89), the azimuth (:38, :88) --
+ * evaluated once per sample when a render kernel needs both functions (the cloud zone lies inside the disk zone). */
+struct DiskPoint { float rc, q, sq, azimuth; bool has_azimuth; };
+
+template <bool LEAN>
+RRT_DEV bool disk_point(v3 p, DiskPoint& d) {           /* false: outside the radial gate, both densities are 0 */
+    const float rc2 = p.x * p.x + 0.0f * 0.0f + p.z * p.z;
+    if (LEAN && !(rc2 >= 1.0f)) return false;          /* rc < 1 < ISCO; keeps sqrt_tame in range */
+    d.rc = Ar<LEAN>::sqrt(rc2);
+    if (d.rc < kIsco || d.rc > kDiskOut) return false;
+    d.q = Ar<LEAN>::div(kIsco, d.rc);                   /* in [0.4, 1] */
+    d.sq = Ar<LEAN>::sqrt(d.q);                         /* == powf(q, 0.5f); q * sq == powf(q, 1.5f) (rrt_math.h) */
+    d.azimuth = 0.0f; d.has_azimuth = false;
+    return true;
+}
+RRT_DEV float disk_azimuth(v3 p, DiskPoint& d) {
+    if (!d.has_azimuth) { d.azimuth = rrt_atan2f(p.z, p.x); d.has_azimuth = true; }
+    return d.azimuth;
+}
+
 template <bool EARLY_OUT, bool LUT>
-RRT_DEV float accretion_density(v3 p, float time, const NoiseLut& L, unsigned* oob) {
+RRT_DEV float accretion_density_at(v3 p, float time, DiskPoint& dp, const NoiseLut& L, unsigned* oob) {
     /* The render kernels (EARLY_OUT) call this only inside the disk zone, |y| < 4 and r < 30 (raymarcher.cu:57), so
      * every division / square root below has tame operands once the radial gate has passed: rc in [10, 25],
      * q = 10/rc in [0.4, 1], thick in [0.5, 0.8], y*y < 16 (a y*y too small for the bare division to be exact,
      * < 2^-100, feeds exp(-0) = 1 either way). */
     constexpr bool LEAN = EARLY_OUT;
-    const float rc2 = p.x * p.x + 0.0f * 0.0f + p.z * p.z;
-    if (LEAN && !(rc2 >= 1.0f)) return 0.0f;                      /* rc < 1 < ISCO; keeps sqrt_tame in range */
-    const float rc = Ar<LEAN>::sqrt(rc2);
-    if (rc < kIsco || rc > kDiskOut) return 0.0f;
+    const float rc = dp.rc, q = dp.q;
 
     float rim = 1.0f;                                   /* taper of the outer 15 % (:25-30) */
     const float rim_from = kDiskOut * 0.85f;
@@ -478,8 +499,7 @@ RRT_DEV float accretion_density(v3 p, float time, const NoiseLut& L, unsigned* o
         rim = 1.0f - Ar<LEAN>::div(rc - rim_from, kDiskOut - rim_from);
         rim *= rim;
     }
-    const float q = Ar<LEAN>::div(kIsco, rc);
-    const float thick = kDiskH * (LEAN ? sqrt_tame(q) : rrt_powf(q, 0.5f));
+    const float thick = kDiskH * dp.sq;                /* DISK_H_M * powf(q, 0.5f) */
     const float slab = rrt_expf(Ar<LEAN>::div(-(p.y * p.y), 2.0f * thick * thick + 1e-7f));
     const float fall = rrt_powf(q, 0.4f);
     const float envelope = slab * fall * rim;
@@ -492,8 +512,8 @@ RRT_DEV float accretion_density(v3 p, float time, const NoiseLut& L, unsigned* o
      */
     if (EARLY_OUT && envelope * (0.02f + 5.0f * 6.0f) <= 0.001f) return 0.0f;
 
-    const float azimuth = rrt_atan2f(p.z, p.x);
-    const float kepler = 3.5f * (LEAN ? q * sqrt_tame(q) : rrt_powf(q, 1.5f));
+    const float azimuth = disk_azimuth(p, dp);
+    const float kepler = 3.5f * (q * dp.sq);            /* 3.5f * powf(q, 1.5f) */
     const float turned = azimuth - time * kepler;
     float sn, cs;
     rrt_sincosf(turned, &sn, &cs);
@@ -523,26 +543,27 @@ RRT_DEV float accretion_density(v3 p, float time, const NoiseLut& L, unsigned* o
     streak = fmin2(6.0f, streak);
     return envelope * (0.02f + 5.0f * streak);
 }
+template <bool EARLY_OUT, bool LUT>
+RRT_DEV float accretion_density(v3 p, float time, const NoiseLut& L, unsigned* oob) {
+    DiskPoint dp;
+    if (!disk_point<EARLY_OUT>(p, dp)) return 0.0f;
+    return accretion_density_at<EARLY_OUT, LUT>(p, time, dp, L, oob);
+}
 
 /* getDustCloudDensity, densities.h:69-132.  LEAN (the render kernels, which call it only inside the cloud zone
  * |y| < 0.75, r < 25: raymarcher.cu:58): the same tame-operand argument as in accretion_density. */
 template <bool LUT, bool LEAN = true>
-RRT_DEV float dust_density(v3 p, float time, const NoiseLut& L, unsigned* oob) {
-    const float rc2 = p.x * p.x + 0.0f * 0.0f + p.z * p.z;
-    if (LEAN && !(rc2 >= 1.0f)) return 0.0f;
-    const float rc = Ar<LEAN>::sqrt(rc2);
-    if (rc < kIsco || rc > kDiskOut) return 0.0f;
-
+RRT_DEV float dust_density_at(v3 p, float time, DiskPoint& dp, const NoiseLut& L, unsigned* oob) {
+    const float rc = dp.rc, q = dp.q;
     const float outer = smoothstep_t<LEAN>(kDiskOut, kDiskOut * 0.8f, rc);
     const float inner = smoothstep_t<LEAN>(kIsco, kIsco + 5.0f, rc);
-    const float q = Ar<LEAN>::div(kIsco, rc);
     const float thick = kCloudH * 0.5f * rrt_powf(q, 0.2f);
     const float slab = rrt_expf(Ar<LEAN>::div(-(p.y * p.y), 2.0f * thick * thick + 1e-7f));
     const float envelope = slab * outer * inner;
     if (envelope < 0.001f) return 0.0f;                 /* densities.h:85 */
 
-    const float azimuth = rrt_atan2f(p.z, p.x);
-    const float kepler = LEAN ? q * sqrt_tame(q) : rrt_powf(q, 1.5f);     /* 1.0f * pow(...) */
+    const float azimuth = disk_azimuth(p, dp);
+    const float kepler = q * dp.sq;                     /* 1.0f * powf(q, 1.5f) */
     const float sheared = azimuth - time * kepler;
 
     const v3 sc = mk(rc * 0.8f, p.y * 15.0f, sheared * 10.0f);     /* `coords`, :93 */
@@ -605,6 +626,24 @@ RRT_DEV float dust_density(v3 p, float time, const NoiseLut& L, unsigned* oob) {
     const float detail = fbm2_sel<LUT>(mk(dc.x + 0.0f, dc.y + time * 0.5f, dc.z + 0.0f), L, from_table & 256u, false, oob);
     strands *= (0.6f + 0.4f * detail);
     return envelope * strands * 12.0f;
+}
+template <bool LUT, bool LEAN = true>
+RRT_DEV float dust_density(v3 p, float time, const NoiseLut& L, unsigned* oob) {
+    DiskPoint dp;
+    if (!disk_point<LEAN>(p, dp)) return 0.0f;
+    return dust_density_at<LUT, LEAN>(p, time, dp, L, oob);
+}
+
+/* Both densities of one in-zone sample as the render kernels need them (raymarcher.cu:68-69): the position-only
+ * terms are shared (DiskPoint). */
+template <bool LUT>
+RRT_DEV void media_densities(v3 p, float time, bool in_disk, bool in_cloud, const NoiseLut& lut_acc, const NoiseLut& lut_dust,
+                             unsigned* oob, float& d_disk, float& d_cloud) {
+    d_disk = 0.0f; d_cloud = 0.0f;
+    DiskPoint dp;
+    if (!disk_point<true>(p, dp)) return;
+    if (in_disk) d_disk = accretion_density_at<true, LUT>(p, time, dp, lut_acc, oob);
+    if (in_cloud) d_cloud = dust_density_at<LUT, true>(p, time, dp, lut_dust, oob);
 }
 
 /* ---- radiative transfer of one in-zone sample, raymarcher.cu:67-117 ---- */

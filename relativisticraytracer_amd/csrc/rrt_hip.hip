@@ -392,8 +392,8 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
         march_step<SPIN, FAST>(p, vel, h, hh, h6, a.drag_c, r2, r, y);
 
         if (MEDIA != 0 && (in_disk || in_cloud)) {
-            float d_disk = in_disk ? accretion_density<true, MEDIA == 2>(rel_p, a.time, a.lut_acc, oob) : 0.0f;
-            float d_cloud = in_cloud ? dust_density<MEDIA == 2>(rel_p, a.time, a.lut_dust, oob) : 0.0f;
+            float d_disk, d_cloud;
+            media_densities<MEDIA == 2>(rel_p, a.time, in_disk, in_cloud, a.lut_acc, a.lut_dust, oob, d_disk, d_cloud);
             accumulate_sample(acc, d_disk, d_cloud, rel_p, r, vel, h, a.spin);
         }
         if (r > 250.0f && dot(rel_p, vel) > 0.0f) { steps = k + 1; break; }
@@ -616,8 +616,8 @@ __global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
         const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
         const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
         const float h = near_bh ? kHNear : (in_disk ? kHDisk : kHVac);
-        const float d_disk = in_disk ? accretion_density<true, LUT>(rel_p, a.time, a.lut_acc, nullptr) : 0.0f;
-        const float d_cloud = in_cloud ? dust_density<LUT>(rel_p, a.time, a.lut_dust, nullptr) : 0.0f;
+        float d_disk, d_cloud;
+        media_densities<LUT>(rel_p, a.time, in_disk, in_cloud, a.lut_acc, a.lut_dust, nullptr, d_disk, d_cloud);
         float ex, ey, ez, s;
         if (!sample_emission(d_disk, d_cloud, rel_p, r, vel, h, a.spin, ex, ey, ez, s)) {
             ex = 0.f; ey = 0.f; ez = 0.f; s = 1.0f;       /* identity for accumulate_emission */
@@ -837,8 +837,7 @@ __global__ void k_media_lut(int n, const float* p, float time, NoiseLut la, Nois
     const float r = length(q);                           /* the zone tests of raymarcher.cu:57-58 gate the calls */
     const bool in_disk = fabsf(q.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
     const bool in_cloud = fabsf(q.y) < kCloudH * 1.5f && r < kCloudOut;
-    out_disk[i] = in_disk ? accretion_density<true, true>(q, time, la, counts) : 0.0f;
-    out_dust[i] = in_cloud ? dust_density<true>(q, time, ld, counts) : 0.0f;
+    media_densities<true>(q, time, in_disk, in_cloud, la, ld, counts, out_disk[i], out_dust[i]);
 }
 
 /*
