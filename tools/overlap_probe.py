@@ -6,14 +6,15 @@ import relativisticraytracer_amd as rrt
 from relativisticraytracer_amd.sky import synthetic_sky
 w, h, R = 3840, 2160, 16
 K = 24
-tex = rrt.SkyTexture(synthetic_sky()); cam = rrt.CameraState.default(); fx = rrt.CameraEffects()
+tex = rrt.SkyTexture(synthetic_sky())
+nt = rrt.NoiseTable(32.0) if os.environ.get('RRT_TOOL_TABLE', '1') == '1' else None; cam = rrt.CameraState.default(); fx = rrt.CameraEffects()
 pools = [rrt.Workspace(3 << 30), rrt.Workspace(3 << 30)]
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 bufs = [torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda") for _ in range(2)]
 NS = [int(a) for a in sys.argv[1:]] or [8, 4, 2, 1]
 for n in NS:
     for policy, pname in ((0, "auto"),):
-        prms = [rrt.RenderParams(spin=0.9, workspace=p.id, path_policy=policy) for p in pools]
+        prms = [rrt.RenderParams(spin=0.9, workspace=p.id, path_policy=policy, noise_table=nt.id if nt else 0) for p in pools]
         res = {}
         for mode in ("one stream", "two streams"):
             for rep in range(2):

@@ -9,7 +9,8 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 wsmb = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 ws = rrt.Workspace(wsmb << 20) if wsmb else None
 tex = rrt.SkyTexture(synthetic_sky())
-cam = rrt.CameraState.default(); fx = rrt.CameraEffects(); prm = rrt.RenderParams(spin=0.9, workspace=ws.id if ws else 0, path_policy=2)
+nt = rrt.NoiseTable(32.0) if os.environ.get('RRT_TOOL_TABLE', '1') == '1' else None
+cam = rrt.CameraState.default(); fx = rrt.CameraEffects(); prm = rrt.RenderParams(spin=0.9, workspace=ws.id if ws else 0, path_policy=2, noise_table=nt.id if nt else 0)
 buf = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 base = None

@@ -25,6 +25,7 @@ if kt:
             d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in sel
                  if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == big]
             out[key + "_calls"] = len(d); out[key + "_avg_ms"] = sum(d) / len(d)
+            out[key] = [r["Kernel_Name"] for r in sel if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == big][0]
     for r in csv.DictReader(open(kt[0])):
         if "raymarch" in r["Kernel_Name"] and ", true>(" not in r["Kernel_Name"]:
             out["vgpr"] = int(r["VGPR_Count"]); out["sgpr"] = int(r["SGPR_Count"]); out["lds"] = int(r["LDS_Block_Size"])
