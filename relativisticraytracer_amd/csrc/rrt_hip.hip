@@ -446,8 +446,13 @@ __device__ __forceinline__ unsigned wave_index() {
 
 /* Single-kernel path: one ray per lane, media sampled in line (reference raymarch_kernel,
  * src/raymarcher.cu:15-174). */
+#ifdef RRT_EXP_WAVES
+#define RRT_EXP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RRT_EXP_WAVES, RRT_EXP_WAVES)))
+#else
+#define RRT_EXP_WAVES_ATTR
+#endif
 template <bool SPIN, int MEDIA, bool DEBUG, bool FAST>
-__global__ __launch_bounds__(kWGThreads) void raymarch_pixels(const FrameArgs a) {
+__global__ __launch_bounds__(kWGThreads) RRT_EXP_WAVES_ATTR void raymarch_pixels(const FrameArgs a) {
     int x, y, out_row;
     if (!lane_pixel(a, x, y, out_row)) return;
     float uvx, uvy;

@@ -32,6 +32,8 @@ def main(argv=None):
     ap.add_argument("--tile-rows", type=int, default=16)
     ap.add_argument("--workspace-gib", type=int, default=8,
                     help="per-rank pool for the three-pass path, used by launches of <= 1.5 M rays (0 = single kernel only)")
+    ap.add_argument("--no-noise-table", action="store_true",
+                    help="hash every noise3D corner arithmetically (default: lattice-hash tables sized for the sequence's times)")
     ap.add_argument("--out", default=None, help="x.rgba (raw, bottom-up) | dir/ (PPM per frame) | x.mp4 (needs ffmpeg)")
     args = ap.parse_args(argv)
 
@@ -62,7 +64,13 @@ def main(argv=None):
     # with several ranks two frames are in flight (FrameSharder pipeline mode), each with its own half of the pool
     n_slots = 2 if world > 1 else 1
     pools = [rrt.Workspace((args.workspace_gib << 30) // n_slots) for _ in range(n_slots)] if args.workspace_gib > 0 else []
+    # lattice-hash tables for the volumetric noise, covering the times the recording clock will reach (main.cpp:511-516)
+    ntab = None
+    if not args.no_noise_table and not args.no_volumetrics:
+        t_end, _ = camera_paths.recording_clock(max(args.frames, 1), args.fps)
+        ntab = rrt.NoiseTable(float(t_end) + 1.0)
     prms = [rrt.RenderParams(spin=args.spin, volumetrics=0 if args.no_volumetrics else 1,
+                             noise_table=ntab.id if ntab else 0,
                              arith_mode=1 if args.fast else 0, workspace=pools[j].id if pools else 0,
                              path_policy=int(os.environ.get("RRT_PATH_POLICY", "0"))) for j in range(n_slots)]
     path = camera_paths.CameraPath(args.path) if args.path >= 0 else None
@@ -113,6 +121,8 @@ def main(argv=None):
                           "arith_mode": "fast" if args.fast else "strict", "sink": args.out}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if ntab:
+        ntab.destroy()
     tex.destroy()
 
 

@@ -111,6 +111,44 @@ def test_cpp_driver_rccl_gather_path_writes_the_same_frames(tmp_path):
     assert r.returncode == 2 and "device(s) visible" in r.stderr
 
 
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.gpu
+def test_two_gpus_over_rccl_equal_one_gpu(tmp_path):
+    """Needs >= 2 GPUs (skipped on the one-GPU box): both hosts over real RCCL -- rrt_headless --gpus 2 (one process,
+    ncclCommInitAll, grouped send/recv) and headless.py under torch.distributed.run (backend nccl, async gather) --
+    must write the frames of the one-GPU run."""
+    if _gpu_count() < 2:
+        pytest.skip("needs two GPUs")
+    import socket
+    from relativisticraytracer_amd import build
+    exe = build.build_headless()
+    base = ["--width", "320", "--height", "180", "--frames", "6", "--path", "0", "--spin", "0.9", "--all-effects"]
+    one, cpp2, py2 = tmp_path / "one.rgba", tmp_path / "cpp2.rgba", tmp_path / "py2.rgba"
+    subprocess.run([exe] + base + ["--out", str(one)], check=True, capture_output=True)
+    r = subprocess.run([exe] + base + ["--gpus", "2", "--out", str(cpp2)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 2
+    assert open(cpp2, "rb").read() == open(one, "rb").read()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RRT_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        "-m", "relativisticraytracer_amd.headless"] + base + ["--workspace-gib", "2", "--out", str(py2)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(py2, "rb").read() == open(one, "rb").read()
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--width", "640", "--height", "360", "--steps", "3",
+                        "--warmup", "1", "--cpu-stride", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["comm_ranks"] == 2 and "RCCL" in d["config"]["dist_backend"]
+
+
 @pytest.mark.gpu
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` as the driver invokes it (no launcher): bench.py starts the two ranks itself as
