@@ -470,6 +470,42 @@ def test_full_size_frames_sampled_against_oracle(ctx, po, sky, w, h, spin, t, st
     assert got[np.ix_(rows, xs)][..., :3].any()
 
 
+@pytest.mark.parametrize("name,w,h,vol,frame_k,stride", [
+    ("configs[1]: 1080p, skybox only", 1920, 1080, 0, 0, 41),
+    ("configs[4]: 8K, path 0 frame 150, all effects", 7680, 4320, 1, 150, 193),
+    ("configs[4]: 8K, path 0 frame 288 (inside the disk plane), all effects", 7680, 4320, 1, 288, 257),
+])
+def test_baseline_configs_at_full_size_sampled_against_oracle(ctx, po, sky, name, w, h, vol, frame_k, stride):
+    """The BASELINE.json configurations round 1 only ran small or with the default camera: configs[1] (volumetrics off)
+    at its real 1920x1080, and configs[4] (7680x4320, "Gargantua Fly-By" camera path with the recording clock, chromatic
+    aberration on) -- with the noise tables, as the drivers render it.  Every `stride`-th pixel against the oracle."""
+    import torch
+    from relativisticraytracer_amd import camera_paths as cp
+    g, rrt, tex = ctx
+    if frame_k:
+        t, pt = cp.recording_clock(frame_k)
+        cam = cp.CameraPath(0).camera_at(pt)
+        fx = rrt.CameraEffects(useChromaticAberration=True); ofx = po.default_effects(use_ca=1)
+    else:
+        t, cam, fx, ofx = 1.0, rrt.CameraState.default(), rrt.CameraEffects(), po.default_effects()
+    nt = rrt.NoiseTable(14.0) if vol else None
+    try:
+        out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+        rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, volumetrics=vol, noise_table=nt.id if nt else 0))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().reshape(h, w, 4)
+    finally:
+        if nt:
+            nt.destroy()
+    a = cam.as_array()
+    o = po.render(po.camera(a[0], a[1], a[2], a[3]), ofx, po.default_params(spin=0.9, volumetrics=vol, math_mode=po.MATH_PORTABLE),
+                  t, w, h, sky, stride=(stride, stride))["rgba8"]
+    ys = np.arange(0, h, stride); xs = np.arange(0, w, stride)
+    rows = (h - 1 - ys)
+    assert np.array_equal(got[np.ix_(rows, xs)], o[np.ix_(rows, xs)]), name
+    assert got[np.ix_(rows, xs)][..., :3].any()
+
+
 def test_full_size_properties_4k(ctx):
     """BASELINE config at full size: properties that need no oracle.
     Two launches give identical bytes (no races); every alpha is 255; the image is left-right
