@@ -246,6 +246,9 @@ int rrt_unit_media_lut(int n, const float* d_p, float time, int table, float* d_
  * [0] receives the number of mismatching cases, [1..3] one failing case. */
 int rrt_selfcheck_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* stream);
 int rrt_selfcheck_div(unsigned long long n_cases, uint32_t seed, unsigned long long* d_counters, void* stream);
+/* the march's transcendental-free square root (csrc/rrt_device.h: sqrt_seeded) over a range of float bit patterns
+ * and a ladder of seed errors; d_counters[3] receives the number of accepted (checked) cases */
+int rrt_selfcheck_sqrt_seeded(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* stream);
 /* the media code's scaling-free division (csrc/rrt_device.h: rrt_div_tame) on random tame operand pairs */
 int rrt_selfcheck_div_tame(unsigned long long n_cases, uint32_t seed, unsigned long long* d_counters, void* stream);
 

@@ -99,6 +99,7 @@ SYMBOLS = [
     ("rrt_selfcheck_sqrt", _i, [C.c_uint32, C.c_uint32, _vp, _vp]),
     ("rrt_selfcheck_div", _i, [_ull, C.c_uint32, _vp, _vp]),
     ("rrt_selfcheck_div_tame", _i, [_ull, C.c_uint32, _vp, _vp]),
+    ("rrt_selfcheck_sqrt_seeded", _i, [C.c_uint32, C.c_uint32, _vp, _vp]),
     ("rrt_camera_from_angles", _i, [C.POINTER(C.c_float * 3), _f, _f, _cam]),
     ("rrt_catmull_rom", _i, [C.POINTER(C.c_float * 3)] * 4 + [_f, C.POINTER(C.c_float * 3)]),
     ("rrt_lerp_angle", _i, [_f, _f, _f, C.POINTER(_f)]),

@@ -338,6 +338,83 @@ RRT_DEV void integrate_rk4(v3& p, v3& v, float h, float drag_c) {
 }
 
 /*
+ * Correctly rounded sqrt WITHOUT the v_rsq_f32: Goldschmidt iterations from a caller-supplied estimate y0 of
+ * 1/sqrt(x).  A transcendental instruction costs ~13 cycles in a VALU stream on gfx950 (6 ordinary issue slots,
+ * profiles/r02_valu_issue_microbench.txt), and the march always has an excellent estimate at hand: the radius of
+ * RK4 stage k differs from stage k-1's by |v| h/2 at most (<= 1 %), stage 3's from stage 2's and the next step's
+ * from stage 4's by O(h^2) only.  ITERS coupled iterations (3 FMAs each, quadratic: error e -> 1.5 e^2) bring such
+ * an estimate to rounding level, then the same residual correction as sqrt_rsq.  The residual r of the LAST
+ * iteration measures the error that iteration started from; the result is used only if |r| <= kSeedTol, i.e. if
+ * that error was small enough for the iteration to converge to rounding level -- otherwise (first step of a ray,
+ * a huge jump) the caller falls back to sqrt_rsq.  Checked against sqrtf over two full binades x seed errors up to
+ * the tolerance on the GPU (rrt_selfcheck_sqrt_seeded).
+ */
+constexpr float kSeedTol = 1.5e-4f;         /* 1.5 * tol^2 = 3.4e-8 < 2^-24.8 */
+template <int ITERS>
+RRT_DEV bool sqrt_seeded(float x, float y0, float& root, float& inv_root) {
+    float g = x * y0;
+    float h = 0.5f * y0;
+    float r = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        r = __builtin_fmaf(-h, g, 0.5f);
+        g = __builtin_fmaf(g, r, g);
+        h = __builtin_fmaf(h, r, h);
+    }
+    float d = __builtin_fmaf(-g, g, x);
+    root = __builtin_fmaf(d, h, g);
+    inv_root = h + h;
+    return fabsf(r) <= kSeedTol;
+}
+
+/* radius of a stage position: seeded sqrt, rsq-based one where the seed was not good enough, and the
+ * `r < 1` special case of geodesic_acc() */
+template <int ITERS>
+RRT_DEV void stage_radius(float r2, float seed, float& r, float& y) {
+    const bool ok = sqrt_seeded<ITERS>(r2, seed, r, y);
+    if (__builtin_expect(__any(!ok), 0)) {
+        if (!ok) sqrt_rsq(r2, r, y);
+    }
+    if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {   /* r2 == 0 / tiny: keep the seeds finite */
+        if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
+    }
+}
+
+/* integrate_rk4_r with the stage radii from seeded square roots; y_next = 1/|p4|, the estimate for the
+ * radius of the position this step ends at (it differs from p4 by O(h^2)) */
+template <bool SPIN>
+RRT_DEV void integrate_rk4_seeded(v3& p, v3& v, float h, float hh, float h6, float drag_c,
+                                  float r2, float r, float y, float& y_next) {
+    v3 p0 = p, v0 = v;
+    v3 kv1 = geodesic_acc_r<SPIN>(p0, v0, drag_c, r2, r, y);
+    v3 v2 = add(v0, mul(kv1, hh));
+    v3 p2 = add(p0, mul(v0, hh));
+    float r2b = dot(p2, p2), rb, yb;
+    stage_radius<2>(r2b, y, rb, yb);
+    v3 kv2 = geodesic_acc_r<SPIN>(p2, v2, drag_c, r2b, rb, yb);
+    v3 v3_ = add(v0, mul(kv2, hh));
+    v3 p3 = add(p0, mul(v2, hh));
+    float r2c = dot(p3, p3), rc, yc;
+    stage_radius<1>(r2c, yb, rc, yc);
+    v3 kv3 = geodesic_acc_r<SPIN>(p3, v3_, drag_c, r2c, rc, yc);
+    v3 v4 = add(v0, mul(kv3, h));
+    v3 p4 = add(p0, mul(v3_, h));
+    float r2d = dot(p4, p4), rd, yd;
+    stage_radius<2>(r2d, yc, rd, yd);
+    v3 kv4 = geodesic_acc_r<SPIN>(p4, v4, drag_c, r2d, rd, yd);
+    v3 kv_sum, kp_sum;
+    kv_sum.x = kv1.x + __builtin_fmaf(2.0f, kv2.x, __builtin_fmaf(2.0f, kv3.x, kv4.x));
+    kv_sum.y = kv1.y + __builtin_fmaf(2.0f, kv2.y, __builtin_fmaf(2.0f, kv3.y, kv4.y));
+    kv_sum.z = kv1.z + __builtin_fmaf(2.0f, kv2.z, __builtin_fmaf(2.0f, kv3.z, kv4.z));
+    kp_sum.x = v0.x + __builtin_fmaf(2.0f, v2.x, __builtin_fmaf(2.0f, v3_.x, v4.x));
+    kp_sum.y = v0.y + __builtin_fmaf(2.0f, v2.y, __builtin_fmaf(2.0f, v3_.y, v4.y));
+    kp_sum.z = v0.z + __builtin_fmaf(2.0f, v2.z, __builtin_fmaf(2.0f, v3_.z, v4.z));
+    v = add(v0, mul(kv_sum, h6));
+    p = add(p0, mul(kp_sum, h6));
+    y_next = yd;
+}
+
+/*
  * FAST arithmetic mode (rrt_params.arith_mode = RRT_ARITH_FAST; NOT the parity path).
  * Same equations (geodesics.h:30-45, integrators.h:23-59) evaluated the way a GPU compiler with
  * contraction would: fused multiply-adds, 1/r from v_rsq_f32 (1 ulp) instead of correctly rounded

@@ -325,6 +325,23 @@ __device__ __forceinline__ void shade_and_store(const FrameArgs& a, int x, int y
     }
 }
 
+/* The same with the strict square root seeded by an estimate of 1/r (rrt_device.h: sqrt_seeded): `seed` = 1/|p4| of
+ * the previous step, whose end point differs from this position by O(h^2); 0 on a ray's first step (falls back). */
+template <bool FAST>
+__device__ __forceinline__ void march_radius_seeded(v3 rel_p, float seed, float& r2, float& r, float& y) {
+    if (FAST) {
+        r2 = dot_fma(rel_p, rel_p);
+        y = __builtin_amdgcn_rsqf(r2);
+        r = r2 * y;
+        if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {
+            if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
+        }
+    } else {
+        r2 = dot(rel_p, rel_p);
+        stage_radius<1>(r2, seed, r, y);
+    }
+}
+
 /* The step size takes three values (the `in_cloud_zone` arm of raymarcher.cu:62 is unreachable: the
  * cloud zone lies inside the disk zone); h*0.5f and h/6.0f (integrators.h:31,57) are folded per value
  * at compile time. */
@@ -356,9 +373,14 @@ __device__ __forceinline__ void march_radius(v3 rel_p, float& r2, float& r, floa
  * with guards in the unreachable case -- was measured and dropped: the longer basic blocks it leaves let the
  * scheduler interleave independent chains, and on gfx950 a VALU instruction issued 2-6 slots after its producer
  * costs 10-15 % more than one issued right behind it; profiles/README.md, round 2.) */
+#ifndef RRT_SEEDED_SQRT
+#define RRT_SEEDED_SQRT 1
+#endif
 template <bool SPIN, bool FAST>
-__device__ __forceinline__ void march_step(v3& p, v3& vel, float h, float hh, float h6, float drag_c, float r2, float r, float y) {
+__device__ __forceinline__ void march_step(v3& p, v3& vel, float h, float hh, float h6, float drag_c, float r2, float r, float y,
+                                           float& y_seed) {
     if (FAST) integrate_rk4_fast<SPIN>(p, vel, h, hh, h6, drag_c, r2, y);
+    else if (RRT_SEEDED_SQRT) integrate_rk4_seeded<SPIN>(p, vel, h, hh, h6, drag_c, r2, r, y, y_seed);
     else integrate_rk4_r<SPIN>(p, vel, h, hh, h6, drag_c, r2, r, y);
 }
 
@@ -377,10 +399,12 @@ template <bool SPIN, int MEDIA, bool FAST>
 __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel, Radiance& acc, bool& hit, int& i,
                                              unsigned* oob) {
     int steps = i > a.max_steps ? i : a.max_steps;      /* if the loop runs out */
+    float y_seed = 0.0f;                                /* 1/r estimate for the next step's radius; 0: none yet */
     for (int k = i; k < a.max_steps; ++k) {
         const v3 rel_p = p;                             /* p - MASS_POS, MASS_POS = 0 */
         float r2, r, y;
-        march_radius<FAST>(rel_p, r2, r, y);
+        if (RRT_SEEDED_SQRT) march_radius_seeded<FAST>(rel_p, y_seed, r2, r, y);
+        else march_radius<FAST>(rel_p, r2, r, y);
         if (r < kEventHorizon * 1.01f) { hit = true; acc.t = 0.0f; steps = k; break; }
 
         const bool near_bh = r < 18.0f;
@@ -389,7 +413,7 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
         float h, hh, h6;
         zone_step(near_bh, in_disk, h, hh, h6);
 
-        march_step<SPIN, FAST>(p, vel, h, hh, h6, a.drag_c, r2, r, y);
+        march_step<SPIN, FAST>(p, vel, h, hh, h6, a.drag_c, r2, r, y, y_seed);
 
         if (MEDIA != 0 && (in_disk || in_cloud)) {
             float d_disk, d_cloud;
@@ -487,10 +511,12 @@ __global__ __launch_bounds__(kWGThreads) __attribute__((amdgpu_num_sgpr(80))) vo
     unsigned used = kBlockRows;                                   /* rows used in the current block */
     bool overflow = false;                                        /* this lane stopped because the pool is full */
 
+    float y_seed = 0.0f;
     for (; i < a.max_steps; ++i) {
         const v3 rel_p = p;
         float r2, r, yv;
-        march_radius<FAST>(rel_p, r2, r, yv);
+        if (RRT_SEEDED_SQRT) march_radius_seeded<FAST>(rel_p, y_seed, r2, r, yv);
+        else march_radius<FAST>(rel_p, r2, r, yv);
         if (r < kEventHorizon * 1.01f) { hit = true; break; }
 
         const bool near_bh = r < 18.0f;
@@ -567,7 +593,7 @@ __global__ __launch_bounds__(kWGThreads) __attribute__((amdgpu_num_sgpr(80))) vo
             ++used;
         }
 
-        march_step<SPIN, FAST>(p, vel, h, hh, h6, a.drag_c, r2, r, yv);
+        march_step<SPIN, FAST>(p, vel, h, hh, h6, a.drag_c, r2, r, yv, y_seed);
 
         if (need) {                                                /* pre-step position, post-step velocity */
             row_f[0] = rel_p.x; row_f[64] = rel_p.y; row_f[128] = rel_p.z;
@@ -889,6 +915,33 @@ __global__ void k_selfcheck_div(unsigned long long n, uint32_t seed, unsigned lo
         if (rrt_f2u(q2) != rrt_f2u(w2)) { ++bad; counters[1] = rrt_f2u(c); counters[2] = rrt_f2u(d2); counters[3] = 2; }
     }
     if (bad) atomicAdd(counters, (unsigned long long)bad);
+}
+
+/* sqrt_seeded against sqrtf: every float whose bits lie in [lo, hi), with estimates of 1/sqrt(x) that are off by
+ * 0, +-1e-5 ... +-1.2e-2 relative, one and two iterations.  Wherever sqrt_seeded ACCEPTS its result (returns true) the
+ * root must be sqrtf(x) bit for bit.  counters[0] += mismatches, [1]/[2] one failing case (x bits, seed bits),
+ * [3] += accepted cases (so that a test can see the check was not vacuous). */
+__global__ void k_selfcheck_sqrt_seeded(uint32_t lo, uint32_t hi, unsigned long long* counters) {
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const float deltas[10] = {0.0f, 1e-5f, 5e-5f, 1e-4f, 1.4e-4f, 1.6e-4f, 1e-3f, 5e-3f, 1e-2f, 1.2e-2f};
+    unsigned bad = 0;
+    unsigned long long accepted = 0;
+    for (uint64_t b = (uint64_t)lo + idx; b < hi; b += stride) {
+        const float x = rrt_u2f((uint32_t)b);
+        const float want = sqrtf(x);
+        const float y_exact = (float)(1.0 / sqrt((double)x));
+        for (int k = 0; k < 10; ++k) {
+            for (int sgn = -1; sgn <= 1; sgn += 2) {
+                const float seed = y_exact * (1.0f + (float)sgn * deltas[k]);
+                float r1, y1, r2, y2;
+                if (sqrt_seeded<1>(x, seed, r1, y1)) { ++accepted; if (rrt_f2u(r1) != rrt_f2u(want)) { ++bad; counters[1] = b; counters[2] = rrt_f2u(seed); } }
+                if (sqrt_seeded<2>(x, seed, r2, y2)) { ++accepted; if (rrt_f2u(r2) != rrt_f2u(want)) { ++bad; counters[1] = b; counters[2] = rrt_f2u(seed); } }
+            }
+        }
+    }
+    if (bad) atomicAdd(counters, (unsigned long long)bad);
+    atomicAdd(counters + 3, accepted);
 }
 
 /* rrt_div_tame against IEEE `/` on `n` pseudo-random tame operand pairs: |b| in 2^[-40, 40), |a| in 2^[-20, 20) times
@@ -1511,6 +1564,12 @@ int rrt_unit_media_lut(int n, const float* p, float time, int table, float* out_
 int rrt_selfcheck_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* st) {
     if (!d_counters || lo_bits > hi_bits) return RRT_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(k_selfcheck_sqrt, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(st), lo_bits, hi_bits, d_counters);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+int rrt_selfcheck_sqrt_seeded(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* st) {
+    if (!d_counters || lo_bits > hi_bits) return RRT_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(k_selfcheck_sqrt_seeded, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(st), lo_bits, hi_bits, d_counters);
     RRT_HIP(hipGetLastError());
     return RRT_OK;
 }

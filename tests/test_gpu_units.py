@@ -271,6 +271,24 @@ def test_fast_divide_is_correctly_rounded_on_march_operands(g):
     assert int(cnt[0]) == 0, f"{int(cnt[0])} mismatches, e.g. {int(cnt[1]):#x} / {int(cnt[2]):#x}"
 
 
+def test_seeded_sqrt_is_correctly_rounded_whenever_it_accepts(g):
+    """sqrt_seeded (the march's square root without v_rsq: Goldschmidt from the previous stage's 1/r) == IEEE sqrtf
+    for EVERY float of [1, 4) (two binades = every mantissa with either exponent parity) and of [2^14, 2^16), with
+    estimates off by 0 ... +-1.2e-2, one and two iterations, wherever it accepts its own result; and it does accept
+    the estimates the march produces (errors <= 1e-4 with one iteration, <= 1e-2 with two)."""
+    import ctypes as C
+    import torch
+    from relativisticraytracer_amd import _lib
+    for lo in (0x3f800000, 0x3f800000 + (14 << 23)):
+        cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
+        _lib.check(_lib.load().rrt_selfcheck_sqrt_seeded(lo, lo + (2 << 23), C.c_void_p(cnt.data_ptr()), None), "selfcheck_sqrt_seeded")
+        torch.cuda.synchronize()
+        assert int(cnt[0]) == 0, f"{int(cnt[0])} mismatches, e.g. x bits {int(cnt[1]):#x} seed bits {int(cnt[2]):#x}"
+        n = 2 << 23
+        # accepted: 1 iteration for |delta| <= 1.4e-4 (5 deltas x 2 signs, minus the duplicate sign of 0), 2 iterations up to 1e-2
+        assert int(cnt[3]) >= n * (9 + 17) * 0.98, int(cnt[3])
+
+
 def test_media_sqrt_and_divide_cores_are_correctly_rounded(g):
     """The volumetric code's scaling-free sqrt / divide (rrt_device.h: sqrt_tame, rrt_div_tame) == the IEEE forms:
     sqrt on EVERY float of [2^-40, 1) (the range above 1 is covered by the march's check), divide on 2^32 random
