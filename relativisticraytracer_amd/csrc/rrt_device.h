@@ -372,12 +372,24 @@ RRT_DEV bool sqrt_seeded(float x, float y0, float& root, float& inv_root) {
 template <int ITERS>
 RRT_DEV void stage_radius(float r2, float seed, float& r, float& y) {
     const bool ok = sqrt_seeded<ITERS>(r2, seed, r, y);
+#ifndef RRT_STAGE_RADIUS_TWO_TESTS
+    /* An accepted result is the correctly rounded root whatever the magnitude of r2 (the iteration is invariant
+     * under scaling by 4^k), so the `r2 < 1` special case -- there to keep r and the reciprocal finite when r2 is 0,
+     * tiny or NaN, none of which a finite estimate can "converge" to -- only needs looking at when it is rejected. */
+    if (__builtin_expect(__any(!ok), 0)) {
+        if (!ok) {
+            sqrt_rsq(r2, r, y);
+            if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
+        }
+    }
+#else
     if (__builtin_expect(__any(!ok), 0)) {
         if (!ok) sqrt_rsq(r2, r, y);
     }
     if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {   /* r2 == 0 / tiny: keep the seeds finite */
         if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
     }
+#endif
 }
 
 /* integrate_rk4_r with the stage radii from seeded square roots; y_next = 1/|p4|, the estimate for the
