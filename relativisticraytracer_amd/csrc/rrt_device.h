@@ -9,7 +9,9 @@
  *     -ffp-contract=off, so the only fused operations are the explicit fmaf()
  *     calls inside rrt_math.h (the portable transcendentals);
  *   - `/` and sqrtf are correctly rounded (hipcc default
- *     -fhip-fp32-correctly-rounded-divide-sqrt);
+ *     -fhip-fp32-correctly-rounded-divide-sqrt); where the hot loops replace them by cheaper sequences
+ *     (sqrt_rsq, sqrt_seeded, div_seeded, rrt_div_tame) those give the same bits on the operands they are
+ *     used for, and each is checked against the IEEE form on the GPU (rrt_selfcheck_*);
  *   - algebraic shortcuts are taken only where they are exact in binary32
  *     (x - 0 == x, 1*x == x, (0,1,0) x p == (p.z, 0, -p.x), fmod(x,1) ==
  *     x - trunc(x) up to the sign of a zero result, which no consumer observes).
@@ -24,7 +26,7 @@
  * Correctly rounded a / b without hipcc's range scaling: v_rcp_f32 (1 ulp), one Newton refinement, then the
  * Markstein residual corrections -- the FMA core of LLVM's own f32 division, which is what `/` compiles to minus
  * v_div_scale / v_div_fmas / v_div_fixup.  Bit-identical to IEEE `/` whenever those would have been no-ops:
- * b normal with 2^-60 <= |b| <= 2^60, and a == 0 or 2^-60 <= |a / b| <= 2^60 ("tame" operands; checked on 2^33
+ * b normal with 2^-60 <= |b| <= 2^60, and a == 0 or 2^-60 <= |a / b| <= 2^60 ("tame" operands; checked on 2^32
  * random tame pairs, tests/test_gpu_units.py).  10 issue slots instead of ~20.  Used only where the operand
  * ranges are known by construction -- each use says why.
  */
@@ -372,7 +374,6 @@ RRT_DEV bool sqrt_seeded(float x, float y0, float& root, float& inv_root) {
 template <int ITERS>
 RRT_DEV void stage_radius(float r2, float seed, float& r, float& y) {
     const bool ok = sqrt_seeded<ITERS>(r2, seed, r, y);
-#ifndef RRT_STAGE_RADIUS_TWO_TESTS
     /* An accepted result is the correctly rounded root whatever the magnitude of r2 (the iteration is invariant
      * under scaling by 4^k), so the `r2 < 1` special case -- there to keep r and the reciprocal finite when r2 is 0,
      * tiny or NaN, none of which a finite estimate can "converge" to -- only needs looking at when it is rejected. */
@@ -382,14 +383,6 @@ RRT_DEV void stage_radius(float r2, float seed, float& r, float& y) {
             if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
         }
     }
-#else
-    if (__builtin_expect(__any(!ok), 0)) {
-        if (!ok) sqrt_rsq(r2, r, y);
-    }
-    if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {   /* r2 == 0 / tiny: keep the seeds finite */
-        if (!(r2 >= 1.0f)) { r = sqrtf(r2); y = 1.0f; }
-    }
-#endif
 }
 
 /* integrate_rk4_r with the stage radii from seeded square roots; y_next = 1/|p4|, the estimate for the

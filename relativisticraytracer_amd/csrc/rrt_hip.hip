@@ -372,7 +372,8 @@ __device__ __forceinline__ void march_radius(v3 rel_p, float& r2, float& r, floa
  * position.  (A variant without the per-stage `r < 1` guards -- 5 fewer vector instructions per step, repeated
  * with guards in the unreachable case -- was measured and dropped: the longer basic blocks it leaves let the
  * scheduler interleave independent chains, and on gfx950 a VALU instruction issued 2-6 slots after its producer
- * costs 10-15 % more than one issued right behind it; profiles/README.md, round 2.) */
+ * costs 10-15 % more than one issued right behind it; profiles/README.md, round 2.)
+ * -DRRT_SEEDED_SQRT=0 builds the v_rsq-based stage radii instead (A/B: profiles/README.md). */
 #ifndef RRT_SEEDED_SQRT
 #define RRT_SEEDED_SQRT 1
 #endif
@@ -470,13 +471,8 @@ __device__ __forceinline__ unsigned wave_index() {
 
 /* Single-kernel path: one ray per lane, media sampled in line (reference raymarch_kernel,
  * src/raymarcher.cu:15-174). */
-#ifdef RRT_EXP_WAVES
-#define RRT_EXP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RRT_EXP_WAVES, RRT_EXP_WAVES)))
-#else
-#define RRT_EXP_WAVES_ATTR
-#endif
 template <bool SPIN, int MEDIA, bool DEBUG, bool FAST>
-__global__ __launch_bounds__(kWGThreads) RRT_EXP_WAVES_ATTR void raymarch_pixels(const FrameArgs a) {
+__global__ __launch_bounds__(kWGThreads) void raymarch_pixels(const FrameArgs a) {
     int x, y, out_row;
     if (!lane_pixel(a, x, y, out_row)) return;
     float uvx, uvy;
@@ -918,7 +914,7 @@ __global__ void k_selfcheck_div(unsigned long long n, uint32_t seed, unsigned lo
 }
 
 /* sqrt_seeded against sqrtf: every float whose bits lie in [lo, hi), with estimates of 1/sqrt(x) that are off by
- * 0, +-1e-5 ... +-1.2e-2 relative, one and two iterations.  Wherever sqrt_seeded ACCEPTS its result (returns true) the
+ * 0, +-1e-5 ... +-1.2e-2 relative (a fixed ladder plus 16 pseudo-random errors per x), one and two iterations.  Wherever sqrt_seeded ACCEPTS its result (returns true) the
  * root must be sqrtf(x) bit for bit.  counters[0] += mismatches, [1]/[2] one failing case (x bits, seed bits),
  * [3] += accepted cases (so that a test can see the check was not vacuous). */
 __global__ void k_selfcheck_sqrt_seeded(uint32_t lo, uint32_t hi, unsigned long long* counters) {
@@ -931,9 +927,16 @@ __global__ void k_selfcheck_sqrt_seeded(uint32_t lo, uint32_t hi, unsigned long 
         const float x = rrt_u2f((uint32_t)b);
         const float want = sqrtf(x);
         const float y_exact = (float)(1.0 / sqrt((double)x));
-        for (int k = 0; k < 10; ++k) {
+        for (int k = 0; k < 18; ++k) {
             for (int sgn = -1; sgn <= 1; sgn += 2) {
-                const float seed = y_exact * (1.0f + (float)sgn * deltas[k]);
+                /* the ladder, then 8 pseudo-random errors per x: 4 inside the one-iteration tolerance, 4 inside the two-iteration one */
+                float delta;
+                if (k < 10) delta = deltas[k];
+                else {
+                    const uint32_t hsh = mix32((uint32_t)b * 2654435761u + (uint32_t)(k * 2 + (sgn > 0)));
+                    delta = (float)(hsh & 0xffffffu) * (1.0f / 16777216.0f) * (k < 14 ? 1.45e-4f : 9.5e-3f);
+                }
+                const float seed = y_exact * (1.0f + (float)sgn * delta);
                 float r1, y1, r2, y2;
                 if (sqrt_seeded<1>(x, seed, r1, y1)) { ++accepted; if (rrt_f2u(r1) != rrt_f2u(want)) { ++bad; counters[1] = b; counters[2] = rrt_f2u(seed); } }
                 if (sqrt_seeded<2>(x, seed, r2, y2)) { ++accepted; if (rrt_f2u(r2) != rrt_f2u(want)) { ++bad; counters[1] = b; counters[2] = rrt_f2u(seed); } }

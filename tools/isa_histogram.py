@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """dev tool: per-opcode histogram of the hot march loop of a kernel, from the hipcc assembly listing.
 
-    python tools/isa_histogram.py [kernel-substring ...]    (default: the strict no-media / media / march_defer kernels)
+    python tools/isa_histogram.py [kernel-substring ...]    (default: the strict kernels without media, with media, with the noise tables, and the fast one)
 
 Compiles csrc/rrt_hip.hip with the build's own flags + -save-temps into a scratch directory, finds the
 outermost loop of each requested kernel (LLVM annotates every block with its loop header), splits its blocks
@@ -130,7 +130,7 @@ def main():
     dm = demangled(names)
     want = sys.argv[1:] or ["raymarch_pixels<true, 0, false, false>", "raymarch_pixels<false, 0, false, false>",
                             "raymarch_pixels<true, 1, false, false>", "raymarch_pixels<true, 2, false, false>",
-                            "march_defer<true, false>", "raymarch_pixels<true, 0, false, true>"]
+                            "raymarch_pixels<true, 0, false, true>"]
     for w in want:
         for n in names:
             if w in dm[n]:
