@@ -742,31 +742,30 @@ RRT_DEV bool sample_emission(float d_disk, float d_cloud, v3 rel_p, float r, v3 
      * r in [10, 30): the tame range of the lean divisions / square roots (their guards fall back otherwise) */
     ex = 0.f; ey = 0.f; ez = 0.f;
     float opacity = 0.f;
-    const float g = redshift_factor_r<true>(rel_p, r, vel, spin);
-    if (disk_on) {
-        float T = disk_temperature_t<true>(r);
-        const bool tame = T >= 1.0f;                             /* T in [6.6e6, 1.5e7] for r in [10, 30) */
-        float tn = tame ? rrt_div_tame(T, kDiskTempRef) : T / kDiskTempRef;
-        float T_norm = tame ? sqrt_tame(tn) : rrt_powf(tn, 0.5f);
-        float bol_I = rrt_powf(g, 4.0f) * T_norm * d_disk * kDiskLum;
-        float color_t = g * rrt_powf(tn, 0.4f) * 2.5f;
-        ex += bol_I;                                             /* 1.0f * bol_I */
-        ey += fmin2(0.25f, 0.12f * color_t) * bol_I;
-        ez += fmax2(0.0f, 0.01f * (color_t - 2.0f)) * bol_I;
+    const float shift_g = redshift_factor_r<true>(rel_p, r, vel, spin);
+    if (disk_on) {                                               /* thermal disk, raymarcher.cu:76-88 */
+        const float temp = disk_temperature_t<true>(r);
+        const bool tame = temp >= 1.0f;                          /* temp in [6.6e6, 1.5e7] for r in [10, 30) */
+        const float rel_temp = tame ? rrt_div_tame(temp, kDiskTempRef) : temp / kDiskTempRef;
+        const float root_temp = tame ? sqrt_tame(rel_temp) : rrt_powf(rel_temp, 0.5f);
+        const float power = rrt_powf(shift_g, 4.0f) * root_temp * d_disk * kDiskLum;
+        const float hue = shift_g * rrt_powf(rel_temp, 0.4f) * 2.5f;
+        ex += power;                                             /* 1.0f * power */
+        ey += fmin2(0.25f, 0.12f * hue) * power;
+        ez += fmax2(0.0f, 0.01f * (hue - 2.0f)) * power;
         opacity += d_disk * kDiskOpacity;
     }
-    if (dust_on) {
+    if (dust_on) {                                               /* scattering dust, raymarcher.cu:91-105 */
         const float rr = fmax2(r, kIsco);
-        float lighting = 0.5f + 3.0f * rrt_powf(rr < 64.0f ? rrt_div_tame(kIsco, rr) : kIsco / rr, 1.2f);
-        float cloud_I = d_cloud * kCloudLum * lighting;
-        float shift = smoothstep(0.7f, 1.3f, g);
-        ex += 0.60f * cloud_I * lerp(1.2f, 0.8f, shift);
-        ey += 0.65f * cloud_I * lerp(0.8f, 1.1f, shift);
-        ez += 0.80f * cloud_I * lerp(0.6f, 1.4f, shift);
+        const float lit = 0.5f + 3.0f * rrt_powf(rr < 64.0f ? rrt_div_tame(kIsco, rr) : kIsco / rr, 1.2f);
+        const float glow = d_cloud * kCloudLum * lit;
+        const float grade = smoothstep(0.7f, 1.3f, shift_g);
+        ex += 0.60f * glow * lerp(1.2f, 0.8f, grade);
+        ey += 0.65f * glow * lerp(0.8f, 1.1f, grade);
+        ez += 0.80f * glow * lerp(0.6f, 1.4f, grade);
         opacity += d_cloud * kCloudOpacity;
     }
-    float d_tau = opacity * h;
-    step_trans = rrt_expf(-d_tau);
+    step_trans = rrt_expf(-(opacity * h));                       /* Beer-Lambert factor of this step, :107-108 */
     return true;
 }
 

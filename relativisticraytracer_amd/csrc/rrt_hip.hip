@@ -1702,26 +1702,25 @@ int rrt_recording_clock(int frame_k, int fps, float* sim_time, float* path_time)
  * Note the reference's 3.14159f, not PI. */
 int rrt_camera_from_angles(const float pos[3], float yaw, float pitch, rrt_camera* out) {
     if (!pos || !out) return RRT_ERR_INVALID_ARGUMENT;
-    float radYaw = yaw * 3.14159f / 180.0f;
-    float radPitch = pitch * 3.14159f / 180.0f;
-    float fx = std::sin(radYaw) * std::cos(radPitch);
-    float fy = std::sin(radPitch);
-    float fz = std::cos(radYaw) * std::cos(radPitch);
-    float mag = std::sqrt(fx * fx + fy * fy + fz * fz);
-    fx /= mag; fy /= mag; fz /= mag;
-    const float ux = 0.0f, uy = 1.0f, uz = 0.0f;
-    float rx = uy * fz - uz * fy;
-    float ry = uz * fx - ux * fz;
-    float rz = ux * fy - uy * fx;
-    float rMag = std::sqrt(rx * rx + ry * ry + rz * rz);
-    rx /= rMag; ry /= rMag; rz /= rMag;
-    float upx = fy * rz - fz * ry;
-    float upy = fz * rx - fx * rz;
-    float upz = fx * ry - fy * rx;
-    out->pos[0] = pos[0]; out->pos[1] = pos[1]; out->pos[2] = pos[2];
-    out->forward[0] = fx; out->forward[1] = fy; out->forward[2] = fz;
-    out->right[0] = rx; out->right[1] = ry; out->right[2] = rz;
-    out->up[0] = upx; out->up[1] = upy; out->up[2] = upz;
+    /* float arithmetic in the reference's order (its results are pinned by tests/test_camera_paths.py) */
+    const float deg = 3.14159f;                                    /* the reference's literal, not PI */
+    const float a_yaw = yaw * deg / 180.0f, a_pitch = pitch * deg / 180.0f;
+    const float cp = std::cos(a_pitch);
+    float f[3] = {std::sin(a_yaw) * cp, std::sin(a_pitch), std::cos(a_yaw) * cp};
+    const float f_len = std::sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+    for (float& c : f) c /= f_len;
+    const float world_up[3] = {0.0f, 1.0f, 0.0f};
+    auto cross3 = [](const float a[3], const float b[3], float o[3]) {
+        o[0] = a[1] * b[2] - a[2] * b[1];
+        o[1] = a[2] * b[0] - a[0] * b[2];
+        o[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    float side[3], top[3];
+    cross3(world_up, f, side);                                     /* right = worldUp x forward */
+    const float side_len = std::sqrt(side[0] * side[0] + side[1] * side[1] + side[2] * side[2]);
+    for (float& c : side) c /= side_len;
+    cross3(f, side, top);                                          /* up = forward x right */
+    for (int k = 0; k < 3; ++k) { out->pos[k] = pos[k]; out->forward[k] = f[k]; out->right[k] = side[k]; out->up[k] = top[k]; }
     return RRT_OK;
 }
 

@@ -584,7 +584,7 @@ def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
     nt = rrt.NoiseTable(30.0)
     try:
         overflowed = 0
-        for case in range(int(os.environ.get("RRT_SWEEP_CASES", "14"))):      # soak: RRT_SWEEP_CASES=300
+        for case in range(int(os.environ.get("RRT_SWEEP_CASES", "60"))):      # soak: RRT_SWEEP_CASES=600 (run on the round's final build)
             w, h = int(rng.integers(9, 80)), int(rng.integers(5, 48))
             rad = float(np.exp(rng.uniform(np.log(3.0), np.log(120.0))))
             ang = float(rng.uniform(0, 2 * np.pi))
