@@ -162,25 +162,32 @@ struct NoiseLut {
     unsigned last;         /* n_cells - nxy - 1 */
 };
 
-RRT_DEV float noise3d_lut(const NoiseLut& L, v3 p, unsigned* oob) {
+struct LutTap { float4 q0, q1; float ux, uy, uz; };
+/* first half of a table lookup: the two 16-byte loads are issued, nothing waits on them */
+RRT_DEV LutTap lut_fetch(const NoiseLut& L, v3 p, unsigned* oob) {
+    LutTap t;
     float ix = floorf(p.x), iy = floorf(p.y), iz = floorf(p.z);
     float fx = p.x - ix, fy = p.y - iy, fz = p.z - iz;
-    float ux = fx * fx * (3.0f - 2.0f * fx);
-    float uy = fy * fy * (3.0f - 2.0f * fy);
-    float uz = fz * fz * (3.0f - 2.0f * fz);
+    t.ux = fx * fx * (3.0f - 2.0f * fx);
+    t.uy = fy * fy * (3.0f - 2.0f * fy);
+    t.uz = fz * fz * (3.0f - 2.0f * fz);
     const int cx = (int)ix, cy = (int)iy, cz = (int)iz;
     const unsigned want = (unsigned)(__mul24(cz, L.nxy) + __mul24(cy, L.nx) + cx - L.origin);
     const unsigned idx = want < L.last ? want : L.last;
     if (oob && want > L.last) atomicAdd(oob, 1u);
     const char* base = reinterpret_cast<const char*>(L.cells);
-    const float4 q0 = *reinterpret_cast<const float4*>(base + (size_t)(idx << 4));
-    const float4 q1 = *reinterpret_cast<const float4*>(base + (size_t)((idx + (unsigned)L.nxy) << 4));
-    float a = q0.x + ux * q0.y;
-    float b = q0.z + ux * q0.w;
-    float c = q1.x + ux * q1.y;
-    float d = q1.z + ux * q1.w;
-    return lerp(lerp(a, b, uy), lerp(c, d, uy), uz);
+    t.q0 = *reinterpret_cast<const float4*>(base + (size_t)(idx << 4));
+    t.q1 = *reinterpret_cast<const float4*>(base + (size_t)((idx + (unsigned)L.nxy) << 4));
+    return t;
 }
+RRT_DEV float lut_blend(const LutTap& t) {
+    float a = t.q0.x + t.ux * t.q0.y;
+    float b = t.q0.z + t.ux * t.q0.w;
+    float c = t.q1.x + t.ux * t.q1.y;
+    float d = t.q1.z + t.ux * t.q1.w;
+    return lerp(lerp(a, b, t.uy), lerp(c, d, t.uy), t.uz);
+}
+RRT_DEV float noise3d_lut(const NoiseLut& L, v3 p, unsigned* oob) { return lut_blend(lut_fetch(L, p, oob)); }
 
 /* Per-lane distance (in lattice cells at scale 1, x weighted 1/4: a 128-byte line holds 8 x-neighbours) of
  * this lane's noise-space point from the first active lane's; lut_fits(spread, s) is wave-uniform: at `s`
@@ -521,10 +528,30 @@ RRT_DEV float noise3d_sel(v3 p, const NoiseLut& L, bool from_table, unsigned* oo
     return noise3d(p);
 }
 
+/* Two successive table lookups whose positions are both known: their four loads are issued together, so one
+ * memory latency is exposed instead of two (RRT_LUT_PAIRS=0: one after the other). */
+#ifndef RRT_LUT_PAIRS
+#define RRT_LUT_PAIRS 1
+#endif
+RRT_DEV void noise3d_lut_pair(const NoiseLut& L, v3 p0, v3 p1, unsigned* oob, float& n0, float& n1) {
+    const LutTap a = lut_fetch(L, p0, oob);
+    const LutTap b = lut_fetch(L, p1, oob);
+    n0 = lut_blend(a);
+    n1 = lut_blend(b);
+}
+
 /* fbm(p, 2) (math_utils.h:112-121) with a table switch per octave */
 template <bool LUT>
 RRT_DEV float fbm2_sel(v3 p, const NoiseLut& L, bool t0, bool t1, unsigned* oob) {
     float v = 0.0f, a = 0.5f;
+    if (LUT && RRT_LUT_PAIRS && t0 && t1) {
+        float n0, n1;
+        noise3d_lut_pair(L, p, mk(p.x * 2.05f + 10.0f, p.y * 2.05f + 10.0f, p.z * 2.05f + 10.0f), oob, n0, n1);
+        v += a * n0;
+        a *= 0.5f;
+        v += a * n1;
+        return v;
+    }
 #pragma unroll 1
     for (int i = 0; i < 2; ++i) {
         v += a * noise3d_sel<LUT>(p, L, i == 0 ? t0 : t1, oob);
@@ -539,7 +566,14 @@ RRT_DEV float fbm2_sel(v3 p, const NoiseLut& L, bool t0, bool t1, unsigned* oob)
 #define RRT_LUT_ACC_OCT 4
 #endif
 constexpr int kLutAccOctaves = RRT_LUT_ACC_OCT;      /* accretion fbm(.,5): octaves 0..3 */
-constexpr int kLutRidgeOctaves = 3;    /* dust ridge sum: octaves 0..2 */
+#ifndef RRT_LUT_RIDGE_OCT
+#define RRT_LUT_RIDGE_OCT 3
+#endif
+#ifndef RRT_LUT_DETAIL
+#define RRT_LUT_DETAIL 1
+#endif
+constexpr int kLutRidgeOctaves = RRT_LUT_RIDGE_OCT;    /* dust ridge sum: octaves 0..2 */
+constexpr bool kLutDetail = RRT_LUT_DETAIL != 0;        /* first octave of the dust detail fbm */
 
 /*
  * getAccretionDensity, densities.h:20-62.  EARLY_OUT=false, LUT=false is the literal function (unit
@@ -616,7 +650,18 @@ RRT_DEV float accretion_density_at(v3 p, float time, DiskPoint& dp, const NoiseL
     float n = 0.0f, amp = 0.5f;                         /* fbm(at, 5), math_utils.h:112-121 */
 #pragma unroll 1
     for (int o = 0; o < 5; ++o) {
-        n += amp * noise3d_sel<LUT>(at, L, (from_table >> o) & 1u, oob);
+        if (LUT && RRT_LUT_PAIRS && ((from_table >> o) & 3u) == 3u) {     /* this octave and the next: one round trip */
+            const v3 at1 = mk(at.x * 2.05f + 10.0f, at.y * 2.05f + 10.0f, at.z * 2.05f + 10.0f);
+            float n0, n1;
+            noise3d_lut_pair(L, at, at1, oob, n0, n1);
+            n += amp * n0;
+            amp *= 0.5f;
+            n += amp * n1;
+            at = at1;
+            ++o;
+        } else {
+            n += amp * noise3d_sel<LUT>(at, L, (from_table >> o) & 1u, oob);
+        }
         at = mk(at.x * 2.05f + 10.0f, at.y * 2.05f + 10.0f, at.z * 2.05f + 10.0f);
         amp *= 0.5f;
     }
@@ -665,7 +710,7 @@ RRT_DEV float dust_density_at(v3 p, float time, DiskPoint& dp, const NoiseLut& L
             if (lut_fits(sp, cells)) from_table |= 16u << k;
             cells *= 2.1f;
         }
-        if (lut_fits(sp, 4.0f)) from_table |= 256u;             /* the detail fbm's second octave (8.2 cells per unit) is never coherent */
+        if (kLutDetail && lut_fits(sp, 4.0f)) from_table |= 256u;             /* the detail fbm's second octave (8.2 cells per unit) is never coherent */
     }
 
     /* first warp, :95-99: fbm(c, 2), fbm(c + (1,2,3), 2), fbm(c + (4,5,6), 2) with c = sc*0.15
@@ -694,11 +739,22 @@ RRT_DEV float dust_density_at(v3 p, float time, DiskPoint& dp, const NoiseLut& L
     const v3 fc = add(sc, mul(mk(vx, vy, vz), 1.5f));              /* `final_coords`, :108 */
 
     float n = 0.0f, amp = 1.0f, freq = 1.0f;                       /* ridged sum, :111-120 */
+    const unsigned ridge_bits = (from_table >> 4) & ((1u << kLutRidgeOctaves) - 1u);
 #pragma unroll 1
     for (int k = 0; k < 5; ++k) {
-        const float nv = noise3d_sel<LUT>(mul(fc, freq), L, (from_table >> (4 + k)) & 1u & (k < kLutRidgeOctaves ? 1u : 0u), oob);
-        const float wisp = 1.0f - fabsf(nv * 2.0f - 1.0f);
-        n += wisp * amp;
+        if (LUT && RRT_LUT_PAIRS && ((ridge_bits >> k) & 3u) == 3u) {
+            float n0, n1;
+            noise3d_lut_pair(L, mul(fc, freq), mul(fc, freq * 2.1f), oob, n0, n1);
+            n += (1.0f - fabsf(n0 * 2.0f - 1.0f)) * amp;
+            amp *= 0.5f;
+            freq *= 2.1f;
+            n += (1.0f - fabsf(n1 * 2.0f - 1.0f)) * amp;
+            ++k;
+        } else {
+            const float nv = noise3d_sel<LUT>(mul(fc, freq), L, (ridge_bits >> k) & 1u, oob);
+            const float wisp = 1.0f - fabsf(nv * 2.0f - 1.0f);
+            n += wisp * amp;
+        }
         amp *= 0.5f;
         freq *= 2.1f;
     }

@@ -178,7 +178,7 @@ void lut_boxes(double t_max, LutBox& acc, LutBox& dust) {
             r.add(c);
             freq *= 2.1;
         }
-        {                                                      /* :127: (coords + 1.5 w2)*4 + (0, 0.5 t, 0), first octave only */
+        if (rrt::kLutDetail) {                                 /* :127: (coords + 1.5 w2)*4 + (0, 0.5 t, 0), first octave only */
             Interval c[3];
             for (int ax = 0; ax < 3; ++ax) c[ax] = sc[ax].widened(1.5 * 0.76).scaled(4.0);
             c[1] = c[1].shifted(0.0, 0.5 * t_max);
