@@ -18,6 +18,7 @@ REF_FRAMES_PATH = os.path.join(HERE, "_ref", "libref_frames.so")
 
 MATH_LIBM = 0
 MATH_PORTABLE = 1
+MATH_NUDGED_BASE = 16      # + seed: glibc with every transcendental result moved by <= 2-3 ulp (rrt_oracle.c: nudge)
 
 _f = C.c_float
 _i = C.c_int

@@ -33,6 +33,7 @@
  *   RRTO_MATH_LIBM     glibc powf/expf/sinf/cosf/atan2f/asinf (default)
  *   RRTO_MATH_PORTABLE relativisticraytracer_amd/csrc/rrt_math.h -- the exact
  *                      functions the HIP kernels use, for byte-level checks.
+ *   RRTO_MATH_NUDGED_BASE + seed: glibc perturbed by <= 2-4 ulp per call (see below)
  */
 #ifndef RRT_ORACLE_H
 #define RRT_ORACLE_H
@@ -45,6 +46,9 @@ extern "C" {
 
 #define RRTO_MATH_LIBM 0
 #define RRTO_MATH_PORTABLE 1
+/* RRTO_MATH_NUDGED_BASE + seed: glibc with every transcendental result moved by a pseudo-random number of ulps
+ * inside a GPU math library's documented error class (conditioning probes, tests/test_density_conditioning.py) */
+#define RRTO_MATH_NUDGED_BASE 16
 
 typedef struct {
     float pos[3], forward[3], right[3], up[3];     /* include/raymarcher.h:11-16 */
