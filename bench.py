@@ -74,12 +74,30 @@ def cpu_baseline(width, height, spin, stride, sky, cam_arr=None, time_=1.0):
     sel = sel.reshape(-1)
     n = int(sel.sum())
     means = {k: float(r[k][sel].mean()) for k in ("steps", "n_noise", "n_dens", "n_samples")}
-    return {"value": n / dt / 1e6, "unit": "Mrays/s", "cores": nthreads, "kind": "port",
+    port = {"value": n / dt / 1e6, "unit": "Mrays/s", "cores": nthreads, "kind": "port",
             "cpu_model": cpu_model,
             "build": "gcc -O3 -march=native -ffp-contract=off -fopenmp" if native else
                      "gcc -O2 -mfma -ffp-contract=off -fopenmp",
             "sample": f"every {stride}th pixel in x and y of the same {width}x{height} frame "
-                      f"({n} rays, {dt:.1f} s wall, oracle/rrt_oracle.c, libm math, OpenMP dynamic rows)"}, means
+                      f"({n} rays, {dt:.1f} s wall, oracle/rrt_oracle.c, libm math, OpenMP dynamic rows)"}
+    if not po.ref_frames_available():
+        return port, means
+    # oracle/_ref/libref_frames.so = the REFERENCE's own raymarch_kernel body (and headers), compiled by g++ in the
+    # build container where /root/reference lies (oracle/Makefile), one call per pixel under the same OpenMP loop:
+    # the reference's CPU path on the same sample.  Its step counts must equal the port's (both libm).
+    fx = po.default_effects()
+    t0 = time.perf_counter()
+    rr = po.ref_render(a, fx, spin, 1, time_, width, height, sky, n_threads=nthreads, stride=(stride, stride))
+    dtr = time.perf_counter() - t0
+    same_steps = bool(np.array_equal(rr["steps"][sel], r["steps"][sel]))
+    return {"value": n / dtr / 1e6, "unit": "Mrays/s", "cores": nthreads, "kind": "reference",
+            "cpu_model": cpu_model,
+            "build": "g++ -O2 -ffp-contract=off -fopenmp on /root/reference/src/raymarcher.cu:15-174 + include/*.h "
+                     "(oracle/Makefile ref; harness: launch indices, tex2D = the documented sky filter)",
+            "sample": f"every {stride}th pixel in x and y of the same {width}x{height} frame "
+                      f"({n} rays, {dtr:.1f} s wall, the reference's raymarch_kernel called per pixel, glibc math, "
+                      f"OpenMP dynamic rows)",
+            "step_counts_equal_port": same_steps, "port": port}, means
 
 
 def self_launch(n, argv):

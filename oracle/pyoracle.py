@@ -285,13 +285,14 @@ def ref_frames_available():
     return os.path.exists(REF_FRAMES_PATH)
 
 
-def ref_render(cam_arr, fx, spin, volumetrics, time, width, height, sky, frac_bits=8, n_threads=0):
-    """One frame from the REFERENCE's own raymarch_kernel body (oracle/_ref/libref_frames.so, build
-    container only; oracle/ref_frames.cpp).  `cam_arr` is the 4x3 basis, `fx` an Effects.
+def ref_render(cam_arr, fx, spin, volumetrics, time, width, height, sky, frac_bits=8, n_threads=0, stride=(1, 1)):
+    """One frame from the REFERENCE's own raymarch_kernel body (oracle/_ref/libref_frames.so, compiled in the
+    build container from /root/reference; oracle/ref_frames.cpp).  `cam_arr` is the 4x3 basis, `fx` an Effects;
+    `stride` = (sx, sy) renders every sx-th column of every sy-th row only.
     Returns {"rgba8": (h, w, 4) uint8 bottom-up, "steps": (h*w,) int32 top-down}."""
     lib()                                   # librrt_oracle.so (the sampler) must be loaded first
     dll = C.CDLL(REF_FRAMES_PATH)
-    dll.ref_render.restype = _i
+    dll.ref_render_strided.restype = _i
     cam12 = _fa(np.asarray(cam_arr).reshape(12))
     flags = np.array([fx.use_bloom, fx.use_vignette, fx.use_ca, fx.use_lens], np.int32)
     vals = np.array([fx.bloom_threshold, fx.bloom_intensity, fx.vignette_intensity, fx.ca_amount,
@@ -299,9 +300,10 @@ def ref_render(cam_arr, fx, spin, volumetrics, time, width, height, sky, frac_bi
     sky = np.ascontiguousarray(sky, dtype=np.uint8)
     rgba8 = np.zeros((height, width, 4), np.uint8)
     steps = np.zeros(width * height, np.int32)
-    rc = dll.ref_render(_p(cam12), flags.ctypes.data_as(_ip), _p(vals), _f(spin), int(volumetrics), _f(time),
-                        width, height, sky.ctypes.data_as(_u8p), sky.shape[1], sky.shape[0], int(frac_bits),
-                        rgba8.ctypes.data_as(_u8p), steps.ctypes.data_as(_ip), int(n_threads))
+    rc = dll.ref_render_strided(_p(cam12), flags.ctypes.data_as(_ip), _p(vals), _f(spin), int(volumetrics), _f(time),
+                                width, height, sky.ctypes.data_as(_u8p), sky.shape[1], sky.shape[0], int(frac_bits),
+                                rgba8.ctypes.data_as(_u8p), steps.ctypes.data_as(_ip), int(n_threads),
+                                int(stride[0]), int(stride[1]))
     if rc != 0:
         raise ValueError("ref_render: bad arguments")
     return {"rgba8": rgba8, "steps": steps}

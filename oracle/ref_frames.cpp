@@ -45,10 +45,11 @@ template <> float4 tex2D<float4>(cudaTextureObject_t tex, float x, float y) {
     return make_float4(o[0], o[1], o[2], o[3]);
 }
 
-extern "C" int ref_render(const float* cam12, const int32_t* fx_flags4, const float* fx_vals5, float spin,
-                          int volumetrics, float time, int width, int height, const uint8_t* sky, int sw, int sh,
-                          int frac_bits, uint8_t* rgba8, int32_t* steps, int n_threads) {
-    if (!cam12 || !fx_flags4 || !fx_vals5 || !sky || !rgba8 || width <= 0 || height <= 0) return -1;
+/* every `sy`-th row and `sx`-th column of the frame (the others are left untouched): bench.py's CPU-baseline sample */
+extern "C" int ref_render_strided(const float* cam12, const int32_t* fx_flags4, const float* fx_vals5, float spin,
+                                  int volumetrics, float time, int width, int height, const uint8_t* sky, int sw, int sh,
+                                  int frac_bits, uint8_t* rgba8, int32_t* steps, int n_threads, int sx, int sy) {
+    if (!cam12 || !fx_flags4 || !fx_vals5 || !sky || !rgba8 || width <= 0 || height <= 0 || sx <= 0 || sy <= 0) return -1;
     CameraState cam;
     cam.pos = make_float3(cam12[0], cam12[1], cam12[2]);
     cam.forward = make_float3(cam12[3], cam12[4], cam12[5]);
@@ -62,13 +63,15 @@ extern "C" int ref_render(const float* cam12, const int32_t* fx_flags4, const fl
     SkyImage img = {sky, sw, sh, frac_bits};
     const cudaTextureObject_t tex = static_cast<cudaTextureObject_t>(reinterpret_cast<uintptr_t>(&img));
     if (n_threads <= 0) n_threads = omp_get_max_threads();
+    const int rows = (height + sy - 1) / sy;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
-    for (int y = 0; y < height; ++y) {
+    for (int j = 0; j < rows; ++j) {
+        const int y = j * sy;
         ref_spin_value = spin;
         ref_volumetrics = volumetrics;
         blockDim = dim3(1, 1, 1);
         threadIdx = make_uint3(0, 0, 0);
-        for (int x = 0; x < width; ++x) {
+        for (int x = 0; x < width; x += sx) {
             blockIdx = make_uint3((unsigned)x, (unsigned)y, 0);
             ref_step_count = 0;
             raymarch_kernel(reinterpret_cast<uchar4*>(rgba8), width, height, time, cam, tex, fx);
@@ -76,4 +79,11 @@ extern "C" int ref_render(const float* cam12, const int32_t* fx_flags4, const fl
         }
     }
     return 0;
+}
+
+extern "C" int ref_render(const float* cam12, const int32_t* fx_flags4, const float* fx_vals5, float spin,
+                          int volumetrics, float time, int width, int height, const uint8_t* sky, int sw, int sh,
+                          int frac_bits, uint8_t* rgba8, int32_t* steps, int n_threads) {
+    return ref_render_strided(cam12, fx_flags4, fx_vals5, spin, volumetrics, time, width, height, sky, sw, sh, frac_bits,
+                              rgba8, steps, n_threads, 1, 1);
 }

@@ -1660,29 +1660,27 @@ int rrt_path_keyframes(int idx, float* out6, int cap_keys) {
     return RRT_OK;
 }
 
-/* PathController::getInterpolatedState, src/main.cpp:176-203 */
+/* Camera of a built-in path at path time t -- what PathController::getInterpolatedState (src/main.cpp:176-203)
+ * returns: the end poses hold outside the keyed interval; inside, the position is the Catmull-Rom spline through
+ * the segment's two keys and their neighbours (the end keys stand in for the missing neighbour), the angles go the
+ * short way round (lerp_angle), all with the segment parameter (t - t_from) / (t_to - t_from) in binary32. */
 int rrt_path_camera_at(int idx, float t, rrt_camera* out) {
     if (idx < 0 || idx >= 3 || !out) return RRT_ERR_INVALID_ARGUMENT;
-    const Path& P = kPaths[idx];
-    const Key* k = P.keys;
-    const int n = P.n;
-    auto from_key = [&](const Key& q) { float pos[3] = {q.x, q.y, q.z}; return rrt_camera_from_angles(pos, q.yaw, q.pitch, out); };
-    if (t <= k[0].time) return from_key(k[0]);
-    if (t >= k[n - 1].time) return from_key(k[n - 1]);
-    for (int i = 0; i < n - 1; ++i) {
-        if (t >= k[i].time && t <= k[i + 1].time) {
-            float factor = (t - k[i].time) / (k[i + 1].time - k[i].time);
-            int i0 = i - 1 > 0 ? i - 1 : 0, i1 = i, i2 = i + 1, i3 = i + 2 < n - 1 ? i + 2 : n - 1;
-            float a[3] = {k[i0].x, k[i0].y, k[i0].z}, b[3] = {k[i1].x, k[i1].y, k[i1].z};
-            float c[3] = {k[i2].x, k[i2].y, k[i2].z}, d[3] = {k[i3].x, k[i3].y, k[i3].z};
-            float pos[3];
-            rrt_catmull_rom(a, b, c, d, factor, pos);
-            float yaw = lerp_angle_f(k[i1].yaw, k[i2].yaw, factor);
-            float pitch = lerp_angle_f(k[i1].pitch, k[i2].pitch, factor);
-            return rrt_camera_from_angles(pos, yaw, pitch, out);
-        }
-    }
-    return from_key(k[n - 1]);
+    const Key* key = kPaths[idx].keys;
+    const int last = kPaths[idx].n - 1;
+    auto pose_of = [&](const Key& q) { return rrt_camera_from_angles(&q.x, q.yaw, q.pitch, out); };
+    if (t <= key[0].time) return pose_of(key[0]);
+    if (t >= key[last].time) return pose_of(key[last]);
+    int seg = -1;                                           /* first segment whose closed interval holds t */
+    for (int i = 0; i < last && seg < 0; ++i)
+        if (t >= key[i].time && t <= key[i + 1].time) seg = i;
+    if (seg < 0) return pose_of(key[last]);                 /* t is NaN */
+    const Key &from = key[seg], &to = key[seg + 1];
+    const Key &before = key[seg > 0 ? seg - 1 : 0], &after = key[seg + 2 < last ? seg + 2 : last];
+    const float s = (t - from.time) / (to.time - from.time);
+    float pos[3];
+    rrt_catmull_rom(&before.x, &from.x, &to.x, &after.x, s, pos);   /* Key holds x, y, z contiguously */
+    return rrt_camera_from_angles(pos, lerp_angle_f(from.yaw, to.yaw, s), lerp_angle_f(from.pitch, to.pitch, s), out);
 }
 
 /* The recording clock of the reference's main loop (src/main.cpp:511-516): dt = 1.0f / fps,
