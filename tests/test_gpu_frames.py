@@ -579,12 +579,14 @@ def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
     a starved pool, and interleaved tile shards must all give the oracle's bytes (portable math mode)."""
     import torch
     g, rrt, tex = ctx
-    rng = np.random.default_rng(20261004)
+    rng = np.random.default_rng(int(os.environ.get("RRT_SWEEP_SEED", "20261004")))     # soaks vary the seed
     ample, starved = rrt.Workspace(512 << 20), rrt.Workspace(13 << 20)     # 13 MiB: the smallest useful pool
     nt = rrt.NoiseTable(30.0)
     try:
         overflowed = 0
         for case in range(int(os.environ.get("RRT_SWEEP_CASES", "60"))):      # soak: RRT_SWEEP_CASES=600 (run on the round's final build)
+            if case % 100 == 99:
+                print(f"sweep: {case + 1} scenes", flush=True)            # visible with -s: long soaks show progress
             w, h = int(rng.integers(9, 80)), int(rng.integers(5, 48))
             rad = float(np.exp(rng.uniform(np.log(3.0), np.log(120.0))))
             ang = float(rng.uniform(0, 2 * np.pi))
