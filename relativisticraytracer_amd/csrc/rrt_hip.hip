@@ -450,9 +450,28 @@ __device__ __forceinline__ int row_block() {
     const int nb = gridDim.y, j = blockIdx.y, mid = (nb - 1) >> 1;
     return (j & 1) ? mid + ((j + 1) >> 1) : mid - (j >> 1);
 }
+/* Workgroups go to the 8 XCDs round-robin in linear-id order (statically: ids = k mod 8 all run on one XCD), and
+ * each XCD has its own L2.  RRT_XCD_RUN = L > 0 deals the tile columns of a grid row out so that the workgroups
+ * sharing an XCD cover runs of L adjacent columns (a bijection inside every group of 8 L workgroups; it changes which
+ * workgroup renders a tile, no pixel).  Measured (profiles/r02_xcd_columns_ab.txt): one contiguous run per XCD -- the
+ * usual GEMM recipe -- is 1.5-2x SLOWER here, because an XCD then owns a vertical stripe of the image and the
+ * stripes through the hole and the disk cost several times the outer ones: the round-robin interleave is what
+ * balances this kernel.  Default 0 = identity. */
+#ifndef RRT_XCD_RUN
+#define RRT_XCD_RUN 0
+#endif
+__device__ __forceinline__ int tile_column() {
+    const int bx = blockIdx.x;
+    if (RRT_XCD_RUN <= 0) return bx;
+    constexpr int L = RRT_XCD_RUN > 0 ? RRT_XCD_RUN : 1, G = 8 * L;
+    const int base = (bx / G) * G;
+    if (base + G > (int)gridDim.x) return bx;                 /* the ragged last group keeps its place */
+    const unsigned id = blockIdx.y * gridDim.x + bx;          /* dispatch order: id % 8 labels the XCD */
+    return base + (int)(id & 7u) * L + (((bx - base) >> 3) % L);
+}
 __device__ __forceinline__ bool lane_pixel(const FrameArgs& a, int& x, int& y, int& out_row) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    x = blockIdx.x * kWGPixX + (wave & 1) * kTileW + (lane & (kTileW - 1));
+    x = tile_column() * kWGPixX + (wave & 1) * kTileW + (lane & (kTileW - 1));
     const int lr = row_block() * kWGPixY + (wave >> 1) * kTileH + lane / kTileW;
     return x < a.width && map_row(a.rows, a.height, lr, y, out_row);
 }
