@@ -176,7 +176,9 @@ int rrt_launch_raymarch_compat(void* d_out_rgba8, int width, int height, float t
 
 /* ---- the hot path.  Replaces launch_raymarch, reference include/raymarcher.h:19 /
  *      src/raymarcher.cu:176-180.  Writes width*height RGBA8 pixels, alpha 255,
- *      bottom-up rows, to d_out_rgba8.  prm == NULL -> config.h defaults. ---- */
+ *      bottom-up rows, to d_out_rgba8.  prm == NULL -> config.h defaults.
+ *      Size limits (RRT_ERR_INVALID_ARGUMENT beyond them): width*height < 2^31 pixels, height <= 524 280
+ *      (65 535 row-blocks of 8 rows, HIP's gridDim.y; the reference's 16x16 launch stops at 1 048 560). ---- */
 int rrt_launch_raymarch(void* d_out_rgba8, int width, int height, float time,
                         const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx,
                         const rrt_params* prm, void* stream);

@@ -442,6 +442,7 @@ constexpr int kWGThreads = 64 * kWGWaves;
 constexpr int kTileW = RRT_TILE_W, kTileH = 64 / kTileW;
 static_assert(kTileW * kTileH == 64 && (kTileW & (kTileW - 1)) == 0, "a wave tile is 64 pixels, power-of-two wide");
 constexpr int kWGPixX = kWGWaves == 4 ? 2 * kTileW : kTileW, kWGPixY = kWGWaves == 4 ? 2 * kTileH : kTileH;
+constexpr int kMaxGridY = 65535;               /* HIP's limit for gridDim.y: a launch covers at most kMaxGridY * kWGPixY rows */
 
 /* Workgroups are dispatched in blockIdx order; the rows through the middle of the frame hold the
  * longest rays (shadow edge, disk), so row-blocks are visited from the middle outwards: mid, mid+1,
@@ -741,23 +742,26 @@ __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArg
 __global__ __launch_bounds__(256) void assemble_tiles_kernel(uchar4* frame, const uchar4* tiles, int width,
                                                             int height, RowMap m) {
     const int x = blockIdx.x * 256 + threadIdx.x;
-    const int lr = blockIdx.y;
-    int y, out_row;
-    if (x >= width || !map_row(m, height, lr, y, out_row)) return;
-    frame[(size_t)(height - 1 - y) * width + x] = tiles[(size_t)out_row * width + x];
+    if (x >= width) return;
+    for (int lr = blockIdx.y; lr < m.n_local_rows; lr += gridDim.y) {        /* gridDim.y is capped at kMaxGridY */
+        int y, out_row;
+        if (map_row(m, height, lr, y, out_row))
+            frame[(size_t)(height - 1 - y) * width + x] = tiles[(size_t)out_row * width + x];
+    }
 }
 
 /* all shards in one launch: `tiles` holds n_shards buffers, `shard_stride` pixels apart */
 __global__ __launch_bounds__(256) void assemble_all_kernel(uchar4* frame, const uchar4* tiles, size_t shard_stride,
                                                           int width, int height, int tile_rows, int n_shards) {
     const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;                               /* image row */
-    if (x >= width || y >= height) return;
-    const int t = y / tile_rows, rr = y - t * tile_rows;
-    const int shard = t % n_shards, k = t / n_shards;
-    const int rows_k = min(tile_rows, height - t * tile_rows);
-    const size_t src_row = (size_t)k * tile_rows + (rows_k - 1 - rr);
-    frame[(size_t)(height - 1 - y) * width + x] = tiles[shard * shard_stride + src_row * width + x];
+    if (x >= width) return;
+    for (int y = blockIdx.y; y < height; y += gridDim.y) {                   /* image row; gridDim.y capped */
+        const int t = y / tile_rows, rr = y - t * tile_rows;
+        const int shard = t % n_shards, k = t / n_shards;
+        const int rows_k = min(tile_rows, height - t * tile_rows);
+        const size_t src_row = (size_t)k * tile_rows + (rows_k - 1 - rr);
+        frame[(size_t)(height - 1 - y) * width + x] = tiles[shard * shard_stride + src_row * width + x];
+    }
 }
 
 /* ------------------------------------------------------------------ unit kernels */
@@ -989,6 +993,7 @@ int check_common(const void* out, int width, int height, const rrt_camera* cam, 
                  const rrt_params* prm) {
     if (!out || !cam || !fx || width <= 0 || height <= 0) return RRT_ERR_INVALID_ARGUMENT;
     if ((long long)width * height > (1ll << 31) - 1) return RRT_ERR_INVALID_ARGUMENT;
+    if (height > kMaxGridY * kWGPixY) return RRT_ERR_INVALID_ARGUMENT;             /* 524 280 rows */
     if (prm) {
         if (prm->max_steps < 0 || prm->sky_frac_bits < 0 || prm->sky_frac_bits > 16) return RRT_ERR_INVALID_ARGUMENT;
         if (!(prm->spin == prm->spin)) return RRT_ERR_INVALID_ARGUMENT;
@@ -1467,7 +1472,7 @@ int rrt_assemble_tiles(void* d_frame, const void* d_tiles, int width, int height
         return RRT_ERR_INVALID_ARGUMENT;
     RowMap m{shard_rows(height, tile_rows, shard, n_shards), 0, tile_rows, shard, n_shards};
     if (m.n_local_rows == 0) return RRT_OK;
-    dim3 grid((width + 255) / 256, m.n_local_rows);
+    dim3 grid((width + 255) / 256, m.n_local_rows < kMaxGridY ? m.n_local_rows : kMaxGridY);
     hipLaunchKernelGGL(assemble_tiles_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<uchar4*>(d_frame), static_cast<const uchar4*>(d_tiles), width, height, m);
     RRT_HIP(hipGetLastError());
@@ -1480,7 +1485,7 @@ int rrt_assemble_all_tiles(void* d_frame, const void* d_tiles_all, size_t shard_
         (shard_stride_bytes & 3) != 0)
         return RRT_ERR_INVALID_ARGUMENT;
     if (shard_stride_bytes / 4 < (size_t)shard_rows(height, tile_rows, 0, n_shards) * width) return RRT_ERR_INVALID_ARGUMENT;
-    dim3 grid((width + 255) / 256, height);
+    dim3 grid((width + 255) / 256, height < kMaxGridY ? height : kMaxGridY);
     hipLaunchKernelGGL(assemble_all_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<uchar4*>(d_frame), static_cast<const uchar4*>(d_tiles_all), shard_stride_bytes / 4,
                        width, height, tile_rows, n_shards);

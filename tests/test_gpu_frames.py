@@ -445,6 +445,40 @@ def test_launch_argument_errors(ctx):
         rrt.launch_raymarch(out, -1, 4, 0.0, cam, tex, fx)
 
 
+def test_extreme_aspect_ratios_and_the_height_limit(ctx, po, sky):
+    """Frames far outside the usual shapes: 8 x 70 001 (more rows than a HIP grid has y-blocks: the assemble kernels
+    stride over rows) and 70 001 x 3.  Shards reassemble to the full frame and sampled pixels equal the oracle's;
+    a frame taller than one launch can cover (65 535 row-blocks of 8 rows) is refused loudly."""
+    import torch
+    g, rrt, tex = ctx
+    cam = rrt.CameraState.default(); fx = rrt.CameraEffects(); prm = rrt.RenderParams(spin=0.9)
+    a = cam.as_array(); ocam = po.camera(a[0], a[1], a[2], a[3])
+    oprm = po.default_params(spin=0.9, math_mode=po.MATH_PORTABLE)
+    for (w, h, sx, sy) in ((8, 70001, 3, 4999), (70001, 3, 4999, 1)):
+        full = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+        rrt.launch_raymarch(full, w, h, 1.0, cam, tex, fx, prm)
+        n_shards, R = 2, 16
+        pad = max(rrt.tile_shard_rows(h, R, s, n_shards) for s in range(n_shards)) * w * 4
+        allbuf = torch.zeros(n_shards * pad, dtype=torch.uint8, device="cuda")
+        one = torch.zeros_like(full)
+        for s in range(n_shards):
+            rrt.launch_raymarch_tiles(allbuf[s * pad:], w, h, R, s, n_shards, 1.0, cam, tex, fx, prm)
+            rrt.assemble_tiles(one, allbuf[s * pad:], w, h, R, s, n_shards)
+        together = torch.zeros_like(full)
+        rrt.assemble_all_tiles(together, allbuf, pad, w, h, R, n_shards)
+        torch.cuda.synchronize()
+        assert torch.equal(one, full) and torch.equal(together, full), (w, h)
+        got = full.cpu().numpy().reshape(h, w, 4)
+        o = po.render(ocam, po.default_effects(), oprm, 1.0, w, h, sky, stride=(sx, sy))["rgba8"]
+        ys = np.arange(0, h, sy); xs = np.arange(0, w, sx)
+        rows = h - 1 - ys
+        assert np.array_equal(got[np.ix_(rows, xs)], o[np.ix_(rows, xs)]), (w, h)
+        assert (got[..., 3] == 255).all()
+    small = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    with pytest.raises(rrt.RRTError):
+        rrt.launch_raymarch(small, 1, 65535 * 8 + 1, 1.0, cam, tex, fx, prm)      # validated before anything is launched
+
+
 @pytest.mark.parametrize("w,h,spin,t,stride", [
     (1920, 1080, 0.9, 1.0, 53),       # BASELINE configs[1]/[2] size
     (3840, 2160, 0.9, 1.0, 97),       # the bench frame (BASELINE metric config)
