@@ -445,6 +445,41 @@ def test_launch_argument_errors(ctx):
         rrt.launch_raymarch(out, -1, 4, 0.0, cam, tex, fx)
 
 
+def test_non_finite_inputs_terminate_and_stay_in_bounds(ctx):
+    """Garbage in must not hang or fault: NaN / Inf / huge camera vectors and times.  Every loop of the path is
+    bounded by max_steps and every table / sky index is clamped or wrapped, so each launch completes, writes alpha
+    255 to every pixel, and a clean frame afterwards is unchanged -- single kernel, noise tables, three-pass pool."""
+    import torch
+    g, rrt, tex = ctx
+    w, h = 64, 40
+    fx = rrt.CameraEffects(useChromaticAberration=True)
+    good = rrt.CameraState.default()
+    want = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+    rrt.launch_raymarch(want, w, h, 1.0, good, tex, fx, rrt.RenderParams(spin=0.9))
+    nan, inf = float("nan"), float("inf")
+    cams = [rrt.CameraState(pos=(nan, 10, -60)), rrt.CameraState(pos=(0, 10, -60), forward=(nan, nan, nan)),
+            rrt.CameraState(pos=(inf, 0, 0)), rrt.CameraState(pos=(1e30, -1e30, 1e30), forward=(0, 0, 1e30)),
+            rrt.CameraState(pos=(12, 0.1, 0), forward=(0, 0, 0), right=(0, 0, 0), up=(0, 0, 0)),
+            rrt.CameraState(pos=(12, 0.1, 0), forward=(inf, 0, 0), right=(0, -inf, 0), up=(0, 0, nan))]
+    ws = rrt.Workspace(64 << 20)
+    nt = rrt.NoiseTable(4.0)
+    try:
+        out = torch.zeros_like(want)
+        for cam in cams + [good]:
+            for t in (1.0, nan, inf, -inf, 3.0e38):
+                for prm in (rrt.RenderParams(spin=0.9), rrt.RenderParams(spin=0.9, noise_table=nt.id),
+                            rrt.RenderParams(spin=0.9, workspace=ws.id, path_policy=2, noise_table=nt.id)):
+                    out.zero_()
+                    rrt.launch_raymarch(out, w, h, t, cam, tex, fx, prm)
+                    torch.cuda.synchronize()
+                    assert bool((out.view(-1, 4)[:, 3] == 255).all())
+        rrt.launch_raymarch(out, w, h, 1.0, good, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id))
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+    finally:
+        nt.destroy(); ws.destroy()
+
+
 def test_extreme_aspect_ratios_and_the_height_limit(ctx, po, sky):
     """Frames far outside the usual shapes: 8 x 70 001 (more rows than a HIP grid has y-blocks: the assemble kernels
     stride over rows) and 70 001 x 3.  Shards reassemble to the full frame and sampled pixels equal the oracle's;
