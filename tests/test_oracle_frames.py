@@ -15,6 +15,8 @@ What pins what:
 import numpy as np
 import pytest
 
+from scene_gen import random_scene
+
 DEFAULT_CAM = ((0, 10, -60), (0.0, -0.17364804, 0.9848078), (1.0, 0.0, -0.0), (0.0, 0.9848078, 0.17364804))
 
 CASES = {   # == tests/golden/make_golden.py FRAME_CASES
@@ -90,33 +92,14 @@ def test_restatement_equals_the_reference_kernel_on_random_scenes(po, sky):
     rng = np.random.default_rng(int(os.environ.get("RRT_SWEEP_SEED", "4711")))
     media_frames = 0
     for case in range(int(os.environ.get("RRT_REF_SWEEP_CASES", "24"))):
-        w, h = int(rng.integers(9, 56)), int(rng.integers(5, 34))
-        rad = float(np.exp(rng.uniform(np.log(3.0), np.log(120.0))))
-        ang = float(rng.uniform(0, 2 * np.pi))
-        height = float(rng.normal(0, 0.15) * rad if case % 2 else rng.normal(0, 0.6))
-        pos = np.array([rad * np.cos(ang), height, rad * np.sin(ang)], np.float32)
-        # forward mostly towards the hole, jittered; an orthonormal basis like getCUDAStateFrom's (right = up x fwd)
-        fwd = -pos / np.linalg.norm(pos) + rng.normal(0, 0.35, 3)
-        fwd = (fwd / np.linalg.norm(fwd)).astype(np.float32)
-        right = np.cross(np.array([0, 1, 0], np.float32), fwd); right = (right / np.linalg.norm(right)).astype(np.float32)
-        up = np.cross(fwd, right).astype(np.float32)
-        cam_arr = np.stack([pos, fwd, right, up]).astype(np.float32)
-        spin = float(rng.choice([0.0, 0.3, 0.9, 0.99, -0.7]))
-        vol = int(rng.random() < 0.85)
-        t = float(np.float32(rng.uniform(0, 30)))
-        fx = po.default_effects(use_bloom=int(rng.integers(2)), use_vignette=int(rng.integers(2)),
-                                use_ca=int(rng.integers(2)), use_lens=int(rng.integers(2)),
-                                bloom_threshold=float(np.float32(rng.uniform(0.3, 1.2))),
-                                bloom_intensity=float(np.float32(rng.uniform(0.1, 1.0))),
-                                vignette_intensity=float(np.float32(rng.uniform(0.1, 0.8))),
-                                ca_amount=float(np.float32(rng.uniform(0.0, 0.01))),
-                                distortion_amount=float(np.float32(rng.uniform(-0.2, 0.2))))
-        ref = po.ref_render(cam_arr, fx, spin, vol, t, w, h, sky)
-        got = po.render(_cam(po, cam_arr), fx, po.default_params(spin=spin, volumetrics=vol, math_mode=po.MATH_LIBM),
-                        t, w, h, sky, want=("rgba8", "diag"))
+        sc = random_scene(rng, case)
+        fx = po.default_effects(**sc["fx"])
+        ref = po.ref_render(sc["cam"], fx, sc["spin"], sc["vol"], sc["t"], sc["w"], sc["h"], sky)
+        prm = po.default_params(spin=sc["spin"], volumetrics=sc["vol"], math_mode=po.MATH_LIBM)
+        got = po.render(_cam(po, sc["cam"]), fx, prm, sc["t"], sc["w"], sc["h"], sky, want=("rgba8", "diag"))
         assert np.array_equal(got["rgba8"], ref["rgba8"]), case
         assert np.array_equal(got["steps"], ref["steps"]), case
-        media_frames += int(vol and got["n_samples"].sum() > 0)
+        media_frames += int(sc["vol"] and got["n_samples"].sum() > 0)
     assert media_frames >= 5            # the sweep does look at the disk
 
 
