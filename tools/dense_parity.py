@@ -34,4 +34,21 @@ for name in (sys.argv[4:] or list(VIEWS)):
     bad_total += bad
     print(f"{name:8s} {w}x{h} stride {stride}: {want.shape[0] * want.shape[1]} rays, oracle {dt:.1f} s, "
           f"pixels with different bytes: {bad}", flush=True)
+    if os.environ.get("RRT_DENSE_REF") == "1" and po.ref_frames_available():
+        # the same pixels from the REFERENCE's own kernel body (oracle/_ref, glibc math): step counts must be equal,
+        # bytes within an LSB except at hard-gate flips
+        steps = torch.zeros(h * w, dtype=torch.int32, device="cuda")
+        rrt.launch_raymarch_debug(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id), steps=steps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rr = po.ref_render(a, po.default_effects(), 0.9, 1, t, w, h, sky, stride=(stride, stride))
+        dt = time.perf_counter() - t0
+        gs = steps.cpu().numpy().reshape(h, w)[np.ix_(ys, xs)]           # diagnostics are top-down
+        rs = rr["steps"].reshape(h, w)[np.ix_(ys, xs)]
+        d = np.abs(got.astype(int) - rr["rgba8"][np.ix_(rows, xs)].astype(int))
+        step_bad = int((gs != rs).sum())
+        bad_total += step_bad
+        print(f"{name:8s} vs the reference kernel body ({dt:.1f} s): rays with a different step count: {step_bad}; "
+              f"bytes differing {int((d > 0).sum())} of {d.size} ({(d > 0).mean():.2e}), by more than 1 LSB "
+              f"{int((d > 1).sum())}, max {int(d.max())}", flush=True)
 sys.exit(1 if bad_total else 0)
