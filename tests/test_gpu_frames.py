@@ -327,6 +327,31 @@ def test_random_scenes_against_the_reference_kernel_live(ctx, po, sky):
     assert media >= 5
 
 
+@pytest.mark.parametrize("w,h,stride", [(3840, 2160, 29), (1920, 1080, 17)])
+def test_baseline_frames_against_the_reference_kernel_live(ctx, po, sky, w, h, stride):
+    """BASELINE's metric frame (4K, a = 0.9, full volumetrics, default camera) and the 1080p one, through the noise
+    tables, against the REFERENCE's kernel body run live on this host at every `stride`-th pixel (the whole 4K frame
+    was compared once: profiles/r02_dense_parity_vs_reference.txt): identical step counts, bytes within one LSB."""
+    import torch
+    if not po.ref_frames_available():
+        pytest.skip("oracle/_ref/libref_frames.so not in this tree")
+    g, rrt, tex = ctx
+    cam = rrt.CameraState.default(); fx = rrt.CameraEffects()
+    nt = rrt.NoiseTable(4.0)
+    try:
+        out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+        steps = torch.zeros(h * w, dtype=torch.int32, device="cuda")
+        rrt.launch_raymarch_debug(out, w, h, 1.0, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id), steps=steps)
+        torch.cuda.synchronize()
+    finally:
+        nt.destroy()
+    ref = po.ref_render(cam.as_array(), po.default_effects(), 0.9, 1, 1.0, w, h, sky, stride=(stride, stride))
+    ys = np.arange(0, h, stride); xs = np.arange(0, w, stride); rows = h - 1 - ys
+    assert np.array_equal(steps.cpu().numpy().reshape(h, w)[np.ix_(ys, xs)], ref["steps"].reshape(h, w)[np.ix_(ys, xs)])
+    d = np.abs(out.cpu().numpy().reshape(h, w, 4)[np.ix_(rows, xs)].astype(int) - ref["rgba8"][np.ix_(rows, xs)].astype(int))
+    assert d.max() <= 1 and (d > 0).mean() <= 1e-3
+
+
 def test_noise_table_path_is_byte_identical(ctx):
     """rrt_params.noise_table: low-octave noise3D calls read their corner hashes from the lattice tables
     whenever a wavefront's rays share a few cells.  Same bytes as the arithmetic path -- on 4K views where the
