@@ -134,8 +134,10 @@ def main():
     ap.add_argument("--no-fast", action="store_true", help="skip the informational RRT_ARITH_FAST leg")
     ap.add_argument("--no-noise-table", action="store_true", help="hash every noise3D corner arithmetically (no lattice tables)")
     ap.add_argument("--no-heavy", action="store_true", help="skip the informational heavy-view leg")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="N > 1: frames rendered / gathered / assembled concurrently per rank (>= 2; 1 = no pipelining)")
     ap.add_argument("--workspace-gib", type=int, default=16,
-                    help="per-rank pool for the three-pass path (N > 1), split between the two frames in flight")
+                    help="per-rank pool for the three-pass path (N > 1), split between the frames in flight")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -175,9 +177,11 @@ def main():
     cam, fx = rrt.CameraState.default(), rrt.CameraEffects()
     # With several ranks every launch is a fraction of the frame; the library then prefers its three-pass
     # path for small launches (rrt_params.path_policy = auto), which needs a caller-owned pool.
-    # N > 1 keeps two frames in flight (FrameSharder pipeline mode), each with its own half of the pool.
-    pipeline = world > 1 and os.environ.get("RRT_NO_PIPELINE", "0") != "1"
-    n_slots = 2 if pipeline else 1
+    # N > 1 keeps --frames-in-flight frames in flight (FrameSharder pipeline mode), each with its own share of the
+    # pool: one rank's share of a 4K frame is only a few rounds of wavefronts, and the next frames fill its drain
+    # (profiles/r02_frames_in_flight.txt: 6.41 / 5.64 / 5.39 / 5.67 ms per frame with 1 / 2 / 3 / 4 at N = 8).
+    pipeline = world > 1 and args.frames_in_flight >= 2 and os.environ.get("RRT_NO_PIPELINE", "0") != "1"
+    n_slots = args.frames_in_flight if pipeline else 1
     pools = ([rrt.Workspace((args.workspace_gib << 30) // n_slots) for _ in range(n_slots)]
              if (world > 1 and args.workspace_gib > 0) else [])
     ws = pools[0] if pools else None
@@ -208,10 +212,10 @@ def main():
     def assemble_all(frame, bufs, stride):
         rrt.assemble_all_tiles(frame, bufs, stride, w, h, R, world)
 
-    # N > 1: frame k+1 is rendered (on a second stream) while frame k is gathered and assembled; the last
-    # frame is flushed (gathered + assembled) inside the timed region, so K timed steps deliver K frames.
+    # N > 1: the following frames are rendered (on their own streams) while frame k is gathered and assembled; the
+    # frames still in flight are flushed (gathered + assembled) inside the timed region, so K timed steps deliver K frames.
     fs = sharding.FrameSharder(w, h, R, rank, world, dev, render, assemble, assemble_all=assemble_all,
-                               pipeline=pipeline)
+                               pipeline=n_slots if pipeline else False)
 
     # Untimed one-off setup, so that even --warmup 0 times steady-state steps: load the code object with a
     # tiny launch, and bring up the RCCL communicator / its peer-to-peer channels with one small collective
@@ -302,7 +306,7 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         k_note = "HIP-event kernel time"
         if fs.pipeline:
-            # two frames in flight: consecutive launches overlap on the device, so a launch's own start-to-end
+            # several frames in flight: consecutive launches overlap on the device, so a launch's own start-to-end
             # time is not its cost; price the rank's share against the whole step instead (gather included)
             k_ms, k_note = ms_per_step, "step time (launches of consecutive frames overlap; gather included)"
         my_rays = sharding.shard_rows(h, R, 0, world) * w
@@ -349,7 +353,7 @@ def main():
             "config": {"workload": f"{w}x{h} Kerr a={args.spin:g} full volumetric disk+dust, default camera "
                                    f"(0,10,-60) yaw 0 pitch -10, t=1.0, default effects, synthetic 2048x1024 sky seed 1",
                        "rays_per_frame": rays, "max_steps": 2000, "arith_mode": "strict (bit-exact vs oracle)",
-                       "parallelism": (f"rowtiles{R}x{world}" + (", two frames in flight (render k+1 overlaps gather/assemble of k)" if fs.pipeline else ""))
+                       "parallelism": (f"rowtiles{R}x{world}" + (", %d frames in flight (the next renders overlap gather/assemble of frame k)" % fs.n_slots if fs.pipeline else ""))
                                       if world > 1 else "single",
                        "path": ("auto: three-pass below 1.5 M rays per launch, %d GiB pool" % args.workspace_gib) if ws else "single kernel",
                        "noise_table": ("lattice-hash tables, t_max 32 s, %.0f MB, built once in %.1f ms (outside the timed region)"

@@ -76,15 +76,15 @@ int fail(const char* what, int rc) {
         if (r_ != ncclSuccess) { fprintf(stderr, "rrt_headless: %s: %s\n", #call, ncclGetErrorString(r_)); return 1; } \
     } while (0)
 
-constexpr int kSlots = 2;      // frames in flight
+constexpr int kMaxSlots = 4;   // capacity of the per-slot arrays; --frames-in-flight picks 1..kMaxSlots of them
 
 struct Device {                // everything one GPU owns
     int id = 0;
     rrt_sky_t sky = 0;
     int noise_table = 0;
-    int pool[kSlots] = {0, 0};
-    hipStream_t stream[kSlots] = {nullptr, nullptr};
-    void* tiles[kSlots] = {nullptr, nullptr};     // this device's shard of a frame
+    int pool[kMaxSlots] = {};
+    hipStream_t stream[kMaxSlots] = {};
+    void* tiles[kMaxSlots] = {};                  // this device's shard of a frame
     int shard_rows = 0;
     ncclComm_t comm = nullptr;
 };
@@ -94,6 +94,9 @@ struct Device {                // everything one GPU owns
 int main(int argc, char** argv) {
     int w = 1000, h = 700, frames = 24, fps = 24, path = -1, sky_seed = 1, all_fx = 0, fast = 0;   // config.h:7-9
     int gpus = 1, tile_rows = 16, workspace_gib = 2, use_table = 1, force_collective = 0;
+    int kSlots = 3;                // frames in flight: frame k renders on stream k mod kSlots while its predecessors are
+                                   // gathered / assembled / copied out (a rank's share of a frame is only a few rounds of
+                                   // wavefronts; 3 measured best at 8 shards of a 4K frame: profiles/r02_frames_in_flight.txt)
     float spin = 0.0f, table_tmax = -1.0f;
     std::string out_path;
     for (int i = 1; i < argc; ++i) {
@@ -102,6 +105,7 @@ int main(int argc, char** argv) {
         if (a == "--width") val(w); else if (a == "--height") val(h); else if (a == "--frames") val(frames);
         else if (a == "--fps") val(fps); else if (a == "--path") val(path); else if (a == "--sky-seed") val(sky_seed);
         else if (a == "--gpus") val(gpus); else if (a == "--tile-rows") val(tile_rows); else if (a == "--workspace-gib") val(workspace_gib);
+        else if (a == "--frames-in-flight") val(kSlots);
         else if (a == "--spin" && i + 1 < argc) spin = (float)atof(argv[++i]);
         else if (a == "--noise-table-tmax" && i + 1 < argc) table_tmax = (float)atof(argv[++i]);
         else if (a == "--no-noise-table") use_table = 0;
@@ -110,7 +114,9 @@ int main(int argc, char** argv) {
         else if (a == "--all-effects") all_fx = 1; else if (a == "--fast") fast = 1;
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
-    if (w <= 0 || h <= 0 || frames < 0 || fps <= 0 || gpus < 1 || tile_rows < 1) { fprintf(stderr, "bad arguments\n"); return 2; }
+    if (w <= 0 || h <= 0 || frames < 0 || fps <= 0 || gpus < 1 || tile_rows < 1 || kSlots < 1 || kSlots > kMaxSlots) {
+        fprintf(stderr, "bad arguments\n"); return 2;
+    }
     int n_dev = 0, rc;
     if ((rc = rrt_device_count(&n_dev)) != RRT_OK) return fail("no GPU", rc);
     if (gpus > n_dev) { fprintf(stderr, "rrt_headless: --gpus %d but %d device(s) visible\n", gpus, n_dev); return 2; }
@@ -159,10 +165,10 @@ int main(int argc, char** argv) {
     }
     // device 0: gathered shards + assembled frame, per slot; pinned host frames for the sink
     HIPCHK(hipSetDevice(0));
-    void* gathered[kSlots] = {nullptr, nullptr};
-    void* frame[kSlots] = {nullptr, nullptr};
-    void* host[kSlots] = {nullptr, nullptr};
-    hipEvent_t done[kSlots];
+    void* gathered[kMaxSlots] = {};
+    void* frame[kMaxSlots] = {};
+    void* host[kMaxSlots] = {};
+    hipEvent_t done[kMaxSlots];
     const size_t frame_bytes = (size_t)w * h * 4;
     for (int s = 0; s < kSlots; ++s) {
         HIPCHK(hipMalloc(&gathered[s], shard_stride * gpus));
@@ -194,7 +200,7 @@ int main(int argc, char** argv) {
         float sim_t = 0.0f, path_t = 0.0f;
         rrt_recording_clock(k, fps, &sim_t, &path_t);
         if (path >= 0 && (rc = rrt_path_camera_at(path, path_t, &cam)) != RRT_OK) return fail("camera", rc);
-        // slot reuse: frame k-2 used the same buffers; its host copy must have been written out
+        // slot reuse: frame k-kSlots used the same buffers; its host copy must have been written out
         if (k > kSlots && deliver(slot)) return 1;
         // 1. every device renders its tiles
         for (int d = 0; d < gpus; ++d) {

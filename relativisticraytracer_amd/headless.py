@@ -30,6 +30,8 @@ def main(argv=None):
     ap.add_argument("--all-effects", action="store_true", help="also enable chromatic aberration (key C)")
     ap.add_argument("--sky", default=None, help="equirectangular image file; default: synthetic sky, seed 1")
     ap.add_argument("--tile-rows", type=int, default=16)
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="several ranks: frames rendered / gathered / assembled concurrently per rank (>= 2)")
     ap.add_argument("--workspace-gib", type=int, default=8,
                     help="per-rank pool for the three-pass path, used by launches of <= 1.5 M rays (0 = single kernel only)")
     ap.add_argument("--no-noise-table", action="store_true",
@@ -61,8 +63,9 @@ def main(argv=None):
     w, h = args.width, args.height
     tex = rrt.SkyTexture(load_sky(args.sky) if args.sky else synthetic_sky())
     fx = rrt.CameraEffects(useChromaticAberration=bool(args.all_effects))
-    # with several ranks two frames are in flight (FrameSharder pipeline mode), each with its own half of the pool
-    n_slots = 2 if world > 1 else 1
+    # with several ranks --frames-in-flight frames are in flight (FrameSharder pipeline mode), each with its own
+    # share of the pool
+    n_slots = max(2, args.frames_in_flight) if world > 1 else 1
     pools = [rrt.Workspace((args.workspace_gib << 30) // n_slots) for _ in range(n_slots)] if args.workspace_gib > 0 else []
     # lattice-hash tables for the volumetric noise, covering the times the recording clock will reach (main.cpp:511-516)
     ntab = None
@@ -85,9 +88,9 @@ def main(argv=None):
     def assemble_all(frame, bufs, stride):
         rrt.assemble_all_tiles(frame, bufs, stride, w, h, args.tile_rows, world)
 
-    # with several ranks frame k+1 renders while frame k is gathered and assembled (frames arrive one step late)
+    # with several ranks the next frames render while frame k is gathered and assembled (frames arrive late, in order)
     fs = sharding.FrameSharder(w, h, args.tile_rows, rank, world, dev, render, assemble, assemble_all=assemble_all,
-                               pipeline=world > 1)
+                               pipeline=n_slots if world > 1 else False)
     sink = sinks.open_sink(args.out, w, h, args.fps) if rank == 0 else None
     host = torch.empty(h * w * 4, dtype=torch.uint8, pin_memory=True) if sink else None
 
@@ -105,9 +108,9 @@ def main(argv=None):
         frame = fs.step()
         if sink and frame is not None:
             deliver(frame)
-    frame = fs.flush()
-    if sink and fs.pipeline:
-        deliver(frame)
+    for frame in fs.drain():                # the frames still in flight, in order
+        if sink:
+            deliver(frame)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

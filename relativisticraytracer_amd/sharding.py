@@ -54,18 +54,19 @@ class FrameSharder:
     """One rank's view of a sharded frame.
 
     render(buf, slot)      fills this rank's tile buffer (a (pad_rows*width*4,) uint8 tensor); `slot`
-                           (0, or 0/1 in pipeline mode) tells the callback which of its per-slot
+                           (0, or 0..n-1 in pipeline mode) tells the callback which of its per-slot
                            resources (e.g. the three-pass pool) belongs to this frame
     assemble(frame, buf, shard)   scatters one shard's buffer into the full frame (rank 0 only)
     assemble_all(frame, all_bufs, stride_bytes)   optional: all shards in one launch
 
-    pipeline=True (world > 1) keeps two frames in flight.  Tile, gather and frame buffers are doubled;
-    frame k is rendered, gathered (async_op: on the communicator's stream) and assembled on stream
-    k mod 2 while frame k+1 is rendered on the other stream, so that (i) the transfer and the
-    collective's latency sit under the next render and (ii) the drain of one frame's kernels -- a
-    rank's share is only a few rounds of wavefronts -- is filled by the next frame's.  step() then
-    returns frame k-1 (None on the first call) and flush() the last one; the returned tensor is valid
-    on the caller's current stream until the second step() after it.
+    pipeline=True (world > 1) keeps two frames in flight, pipeline=n (an int >= 2) n of them.  Tile, gather
+    and frame buffers exist once per slot; frame k is rendered, gathered (async_op: on the communicator's
+    stream) and assembled on stream k mod n while the following frames are rendered on the other streams,
+    so that (i) the transfer and the collective's latency sit under the next renders and (ii) the drain of
+    one frame's kernels -- a rank's share is only a few rounds of wavefronts -- is filled by the next
+    frames'.  step() then returns frame k-(n-1) (None on the first n-1 calls), drain() yields the frames
+    still in flight in order and flush() the last of them; a returned tensor is valid on the caller's
+    current stream until n steps after the one that rendered it.
     Ordering: an async collective starts after the work already queued on the stream it is issued from
     (the render that filled its input); work.wait() makes that stream wait for it, before the assemble
     that reads its output and before the slot's buffers are rendered into again, two steps later.
@@ -83,10 +84,13 @@ class FrameSharder:
         # collective_at_world1: run the gather path even on a one-rank group (self-checks of the RCCL calls
         # on a single GPU); normally a single rank assembles its own buffer directly.
         self.collective = world > 1 or bool(collective_at_world1)
-        self.pipeline = bool(pipeline) and self.collective
-        self.n_slots = 2 if self.pipeline else 1
+        depth = 2 if pipeline is True else int(pipeline or 0)
+        if depth == 1 or depth < 0:
+            raise ValueError("pipeline: False, True (two frames in flight) or the number of frames in flight (>= 2)")
+        self.pipeline = depth >= 2 and self.collective
+        self.n_slots = depth if self.pipeline else 1
         self.k = 0
-        self.pending = None
+        self.pending = []                   # (work, staged, slot) of the frames in flight, oldest first
         on_gpu = torch.device(device).type == "cuda"
         self.streams = [torch.cuda.Stream(device) for _ in range(self.n_slots)] if (self.pipeline and on_gpu) else None
         self.locals = [torch.zeros(self.n_bytes, dtype=torch.uint8, device=device) for _ in range(self.n_slots)]
@@ -145,6 +149,7 @@ class FrameSharder:
                 # no async collectives on this backend: one frame at a time, on every rank
                 self.pipeline = False
                 self.streams = None
+                self.n_slots = 1
         self.gathered_all = self.gathered_alls[0] if self.gathered_alls is not None else None
 
     def _on(self, slot):
@@ -193,7 +198,8 @@ class FrameSharder:
 
     def step(self):
         """Render this rank's tiles, gather to rank 0, assemble there.  Returns the frame on rank 0
-        (pipeline mode: the PREVIOUS step's frame, None on the first call; see flush())."""
+        (pipeline mode with n frames in flight: the frame of n-1 steps ago, None on the first n-1 calls;
+        see drain() / flush())."""
         slot = self.k % self.n_slots
         self.k += 1
         if not self.collective:
@@ -205,14 +211,18 @@ class FrameSharder:
             work, staged = self._start_gather(slot)
         if not self.pipeline:
             return self._finish(work, staged, slot)
-        prev, self.pending = self.pending, (work, staged, slot)
-        if prev is None:
+        self.pending.append((work, staged, slot))
+        if len(self.pending) < self.n_slots:
             return None
-        return self._finish(*prev)
+        return self._finish(*self.pending.pop(0))
+
+    def drain(self):
+        """Complete the frames still in flight (pipeline mode), oldest first; yields each on rank 0 (None elsewhere)."""
+        while self.pending:
+            yield self._finish(*self.pending.pop(0))
 
     def flush(self):
-        """Complete the frame still in flight (pipeline mode); returns the last frame on rank 0."""
-        if self.pending is not None:
-            prev, self.pending = self.pending, None
-            self._finish(*prev)
+        """Complete every frame still in flight; returns the last frame on rank 0."""
+        for _ in self.drain():
+            pass
         return self.frame

@@ -88,7 +88,7 @@ def test_cpp_and_python_drivers_write_the_same_frames(tmp_path):
 @pytest.mark.gpu
 def test_cpp_driver_rccl_gather_path_writes_the_same_frames(tmp_path):
     """rrt_headless is ONE process for N GPUs (ncclCommInitAll, grouped ncclSend/ncclRecv gather into device 0,
-    rrt_assemble_all_tiles, two frames in flight).  On the one-GPU box the same code runs over a one-rank
+    rrt_assemble_all_tiles, three frames in flight by default).  On the one-GPU box the same code runs over a one-rank
     communicator (--force-collective): tiles -> RCCL exchange -> assemble must give the frames of the plain
     single-GPU path, with and without the noise tables and the three-pass pool."""
     from relativisticraytracer_amd import build
@@ -99,7 +99,9 @@ def test_cpp_driver_rccl_gather_path_writes_the_same_frames(tmp_path):
     want = open(ref, "rb").read()
     assert len(want) == 5 * 160 * 90 * 4
     for extra in (["--force-collective"], ["--force-collective", "--tile-rows", "7", "--workspace-gib", "1"],
-                  ["--force-collective", "--no-noise-table", "--workspace-gib", "0"], []):
+                  ["--force-collective", "--no-noise-table", "--workspace-gib", "0"], [],
+                  ["--force-collective", "--frames-in-flight", "1"], ["--force-collective", "--frames-in-flight", "2"],
+                  ["--force-collective", "--frames-in-flight", "4"], ["--frames-in-flight", "4"]):
         out = tmp_path / "v.rgba"
         r = subprocess.run([exe] + base + extra + ["--out", str(out)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -109,6 +111,7 @@ def test_cpp_driver_rccl_gather_path_writes_the_same_frames(tmp_path):
         assert open(out, "rb").read() == want, extra
     r = subprocess.run([exe] + base + ["--gpus", "99"], capture_output=True, text=True)
     assert r.returncode == 2 and "device(s) visible" in r.stderr
+    assert subprocess.run([exe] + base + ["--frames-in-flight", "5"], capture_output=True).returncode == 2
 
 
 def _gpu_count():
@@ -168,8 +171,8 @@ def test_bench_self_launches_its_ranks():
 
 @pytest.mark.gpu
 def test_two_ranks_pipelined_equal_one_rank(tmp_path):
-    """Two ranks sharing the card (gloo rehearsal of the N > 1 path: interleaved tiles, two frames in flight,
-    gather, assemble) write the same 5 frames as one rank."""
+    """Two ranks sharing the card (gloo rehearsal of the N > 1 path: interleaved tiles, three -- the default -- and
+    two frames in flight, gather, assemble) write the same 5 frames as one rank."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     a, b = tmp_path / "one.rgba", tmp_path / "two.rgba"
@@ -177,14 +180,16 @@ def test_two_ranks_pipelined_equal_one_rank(tmp_path):
     subprocess.run([sys.executable, "-m", "relativisticraytracer_amd.headless"] + args + ["--out", str(a)],
                    cwd=ROOT, check=True, capture_output=True)
     env = dict(os.environ, RRT_DIST_BACKEND="gloo")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        "-m", "relativisticraytracer_amd.headless"] + args + ["--out", str(b)],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    meta = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert meta["n_gpus"] == 2 and meta["frames"] == 5
-    assert open(a, "rb").read() == open(b, "rb").read()
+    for extra in ([], ["--frames-in-flight", "2"]):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port),
+                            "-m", "relativisticraytracer_amd.headless"] + args + extra + ["--out", str(b)],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        meta = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert meta["n_gpus"] == 2 and meta["frames"] == 5
+        assert open(a, "rb").read() == open(b, "rb").read(), extra
 
 
 @pytest.mark.gpu

@@ -80,16 +80,18 @@ def _worker(rank, world, port, q, pipeline):
         sh.assemble_numpy(f, buf.numpy().reshape(-1, w, 4), w, h, R, shard, world)
 
     fs = sh.FrameSharder(w, h, R, rank, world, "cpu", render, assemble, pipeline=pipeline)
+    depth = 2 if pipeline is True else int(pipeline or 1)
     got = []
     for k in range(len(times)):
         f = fs.step()
-        if pipeline and k == 0:
-            assert f is None                     # nothing assembled yet: frame 0 is still in flight
+        if k < depth - 1:
+            assert f is None                     # nothing assembled yet: the first frames are still in flight
         elif rank == 0:
             got.append(f.numpy().copy())
-    f = fs.flush()
-    if pipeline and rank == 0:
-        got.append(f.numpy().copy())
+    for f in fs.drain():                         # the frames still in flight, oldest first
+        if rank == 0:
+            got.append(f.numpy().copy())
+    assert fs.flush() is fs.frame
     if rank == 0:
         ok = len(got) == len(times)
         for k, t_sim in enumerate(times):
@@ -100,7 +102,7 @@ def _worker(rank, world, port, q, pipeline):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("pipeline", [False, True])
+@pytest.mark.parametrize("pipeline", [False, True, 3])
 def test_gather_world2_gloo_matches_single_render(pipeline):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -133,15 +135,21 @@ def test_pipelined_step_single_process_gloo():
         def assemble(frame, buf, shard):
             sh.assemble_numpy(frame.numpy().reshape(h, w, 4), buf.numpy().reshape(-1, w, 4), w, h, R, shard, 1)
 
-        for pipeline in (False, True):
+        for pipeline, want in ((False, [1, 2, 3, 4, 5]), (True, [None, 1, 2, 3, 4]), (3, [None, None, 1, 2, 3]),
+                               (4, [None, None, None, 1, 2])):
             n["i"] = 0
             fs = sh.FrameSharder(w, h, R, 0, 1, "cpu", render, assemble, pipeline=pipeline, collective_at_world1=True)
             seen = []
             for _ in range(5):
                 f = fs.step()
                 seen.append(None if f is None else int(f[0]))
+            assert seen == want
+            if pipeline == 3:                   # drain() hands out every frame still in flight, in order
+                assert [int(f[0]) for f in fs.drain()] == [4, 5]
             last = int(fs.flush()[0])
-            assert seen == ([None, 1, 2, 3, 4] if pipeline else [1, 2, 3, 4, 5]) and last == 5
+            assert last == 5
             assert fs.flush() is fs.frame and bool((fs.frame == 5).all())       # idempotent
+        with pytest.raises(ValueError):
+            sh.FrameSharder(w, h, R, 0, 1, "cpu", render, assemble, pipeline=1, collective_at_world1=True)
     finally:
         dist.destroy_process_group()
