@@ -344,6 +344,34 @@ class RefCamera:
     def lerp_angle(self, a, b, t):
         return float(self.dll.ref_lerp_angle(_f(a), _f(b), _f(t)))
 
+    # the reference's camera code of src/main.cpp:125-220 (piped into g++, oracle/ref_main_camera_pre.h)
+    def state_from(self, pos, yaw, pitch):
+        """CameraController::getCUDAStateFrom (main.cpp:141-167) -> (4, 3): pos, forward, right, up."""
+        out = np.zeros((4, 3), np.float32)
+        self.dll.ref_camera_state_from(_p(_fa(pos)), _f(yaw), _f(pitch), _p(out))
+        return out
+
+    def path_state_at(self, path, path_time):
+        """PathController::getInterpolatedState (main.cpp:176-203) at an explicit path time."""
+        out = np.zeros((4, 3), np.float32)
+        if self.dll.ref_path_state_at(int(path), _f(path_time), _p(out)) != 0:
+            raise IndexError(path)
+        return out
+
+    def path_state_at_frame(self, path, frame):
+        """State of 1-based recording frame `frame`: start(), then update(1.0f / RECORDING_FPS) per frame
+        (main.cpp:511-516) -> ((4, 3) state, the controller's own pathTime)."""
+        out = np.zeros((4, 3), np.float32)
+        pt = _f(0)
+        if self.dll.ref_path_state_at_frame(int(path), int(frame), _p(out), C.byref(pt)) != 0:
+            raise IndexError((path, frame))
+        return out, np.float32(pt.value)
+
+    def default_camera(self):
+        out = np.zeros(5, np.float32)
+        self.dll.ref_default_camera(_p(out))
+        return out
+
     def paths(self):
         res = []
         for idx in range(self.dll.ref_path_count()):

@@ -5,8 +5,10 @@
  * compiled where it lies (oracle/Makefile) into oracle/_ref/libref_camera.so.
  * Pins catmull_rom, lerp_angle and the three built-in keyframe tables
  * (camera_paths.cpp:6-73).  CameraController::getCUDAStateFrom and
- * PathController::getInterpolatedState live in src/main.cpp, which needs
- * GLFW/GLAD and cannot be built here: those two stay restatements.
+ * PathController::getInterpolatedState live in src/main.cpp; main.cpp as a
+ * whole needs GLFW/GLAD, but the line range that holds those two structs does
+ * not: it is piped into g++ and linked into the same library (round 3:
+ * ref_main_camera_pre.h, ref_main_camera_post.inc, oracle/Makefile).
  */
 #include <cuda_runtime.h>
 #include "camera_paths.h"

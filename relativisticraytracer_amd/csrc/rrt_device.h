@@ -427,6 +427,138 @@ RRT_DEV void integrate_rk4_seeded(v3& p, v3& v, float h, float hh, float h6, flo
 }
 
 /*
+ * Round 3: the same step with fewer instructions (`integrate_rk4_lean`).  The loop is VALU-issue bound at ~95 % of
+ * all issue slots, so only the instruction COUNT moves it; what was still in the step beyond the arithmetic:
+ *   - `h = 0.5f * y0` at the head of every seeded square root: each root already produces h = y/2 (the Goldschmidt
+ *     half-reciprocal) next to y = h + h, so the pair (y, h) is handed on instead of y alone (-1 per root);
+ *   - the acceptance test moves from the LAST to the FIRST residual, r1 = 1/2 - h0*g0 = (1 - x*y0^2)/2, which measures
+ *     the seed's error e directly (r1 = -e - e^2/2): one iteration leaves 1.5 e^2, so the two-iteration roots accept
+ *     |r1| <= kSeedTol2 = 9e-3 (then the second iteration starts within 1.3e-4 < kSeedTol, the case the one-iteration
+ *     form is checked for) and the one-iteration roots |r1| <= kSeedTol as before.  Testing the first residual also
+ *     closes a hole of the last-residual test: a seed with x*y0^2 ~ 4 converges to MINUS the root with a tiny last
+ *     residual (it needs a radius that doubles within half a step, which no ray does, but it was accepted);
+ *   - the `r < 1` guard of geodesics.h:33 on every acceleration: an ACCEPTED stage radius lies within 1 % of the
+ *     radius its seed came from, and the chain of seeds starts at the loop-top radius, which has passed the horizon
+ *     test r >= 2.02 (or, for the loop-top root itself, at the previous step's last stage): every accepted radius
+ *     is > 1.9, so the guard can only fire on lanes that took the v_rsq fall-back, and is evaluated there (-4 compares);
+ *   - VAC (a compile-time flag for the wave-uniform vacuum step, rrt_hip.hip): h, h/2 and h/6 are literals.
+ * Bits are unchanged: every root is still the correctly rounded one (or the fall-back's), y and h only seed the
+ * Markstein divides, which deliver the correctly rounded quotient from any seed of that quality.
+ */
+constexpr float kSeedTol2 = 9e-3f;          /* first residual of a two-iteration root: 1.5 * (9.05e-3)^2 = 1.23e-4 < kSeedTol */
+
+/* returns REJECTED (the seed was not good enough; NaN included): callers branch on that one predicate only, so a
+ * single v_cmp serves the wave ballot and the lane mask */
+template <int ITERS>
+RRT_DEV bool sqrt_seeded_yh(float x, float y0, float h0, float& root, float& y, float& h_out) {
+    float g = x * y0;
+    float h = h0;
+    float r = __builtin_fmaf(-h, g, 0.5f);
+    const float first = r;
+    g = __builtin_fmaf(g, r, g);
+    h = __builtin_fmaf(h, r, h);
+    if (ITERS == 2) {
+        r = __builtin_fmaf(-h, g, 0.5f);
+        g = __builtin_fmaf(g, r, g);
+        h = __builtin_fmaf(h, r, h);
+    }
+    float d = __builtin_fmaf(-g, g, x);
+    root = __builtin_fmaf(d, h, g);
+    y = h + h;
+    h_out = h;
+    return !(fabsf(first) <= (ITERS == 2 ? kSeedTol2 : kSeedTol));
+}
+
+/* the v_rsq fall-back of a rejected root, with the `r < 1` case of geodesic_acc(); `small` = geodesics.h:33 fires */
+RRT_DEV void radius_fallback(float r2, float& r, float& y, float& h, bool& small) {
+    sqrt_rsq(r2, r, y);
+    h = 0.5f * y;
+    small = false;
+    if (!(r2 >= 1.0f)) {
+        /* r2 in [0, 1): the acceleration is zeroed whatever the seeds are, and y = 0 makes the NEXT root reject its
+         * seed (first residual 1/2), so that a following radius < 1 is seen by its own fall-back; NaN: y = 1 keeps
+         * the arithmetic going (everything is NaN from here on, as in the reference) */
+        small = r2 < 1.0f;
+        r = sqrtf(r2); y = small ? 0.0f : 1.0f; h = 0.5f * y;
+    }
+}
+
+/* returns the wave mask of lanes whose radius is < 1 (geodesics.h:33); 0 unless a lane took the fall-back */
+template <int ITERS>
+RRT_DEV unsigned long long stage_radius_yh(float r2, float y0, float h0, float& r, float& y, float& h) {
+    const bool rejected = sqrt_seeded_yh<ITERS>(r2, y0, h0, r, y, h);
+    unsigned long long small_mask = 0ull;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(rejected) != 0ull, 0)) {
+        bool small = false;
+        if (rejected) radius_fallback(r2, r, y, h, small);
+        small_mask = __builtin_amdgcn_ballot_w64(small);
+    }
+    return small_mask;
+}
+
+/* geodesic_acc_r without the guard; lanes in `small_mask` (only ever set behind radius_fallback) get the zero of
+ * geodesics.h:33.  The mask is a scalar: the straight path pays one s_cmp, no vector instruction. */
+template <bool SPIN>
+RRT_DEV v3 geodesic_acc_ng(v3 p, v3 v, float drag_c, float r2, float r, float y, unsigned long long small_mask) {
+    v3 L = cross(p, v);
+    float L2 = dot(L, L);
+    float y2 = y * y;
+    float y3 = y2 * y;
+    float d2 = r2 * r;
+    float d1 = (r2 * r2) * r;
+    float radial_mag = div_seeded(-3.0f * L2, d1, y3 * y2);
+    v3 acc = mul(p, radial_mag);
+    if (SPIN) {
+        float ds = div_seeded(drag_c, d2, y3);
+        acc.x = acc.x + p.z * ds;
+        acc.z = acc.z + (-p.x) * ds;
+    }
+    if (__builtin_expect(small_mask != 0ull, 0)) {
+        if ((small_mask >> (threadIdx.x & 63)) & 1ull) acc = mk(0.f, 0.f, 0.f);
+    }
+    return acc;
+}
+
+/* One RK4 step (integrators.h:23-59) from the loop-top radius (r2, r, y, h) of the pre-step position; (y_next,
+ * h_next) = the reciprocal radius of the last stage position, the seed of the next step's loop-top root.
+ * The loop-top radius has passed the caller's horizon test (r >= 2.02), so stage 1 needs no `r < 1` case.  VAC: h = STEP_SIZE_M exactly (no zone applies), constants folded. */
+template <bool SPIN, bool VAC>
+RRT_DEV void integrate_rk4_lean(v3& p, v3& v, float h_in, float hh_in, float h6_in, float drag_c,
+                                float r2, float r, float y, float hy, float& y_next, float& h_next) {
+    const float h = VAC ? kStepSize : h_in;
+    const float hh = VAC ? 0.5f * kStepSize : hh_in;
+    const float h6 = VAC ? kStepSize / 6.0f : h6_in;
+    v3 p0 = p, v0 = v;
+    v3 kv1 = geodesic_acc_ng<SPIN>(p0, v0, drag_c, r2, r, y, 0ull);
+    v3 v2 = add(v0, mul(kv1, hh));
+    v3 p2 = add(p0, mul(v0, hh));
+    float r2b = dot(p2, p2), rb, yb, hb;
+    const unsigned long long sb = stage_radius_yh<2>(r2b, y, hy, rb, yb, hb);
+    v3 kv2 = geodesic_acc_ng<SPIN>(p2, v2, drag_c, r2b, rb, yb, sb);
+    v3 v3_ = add(v0, mul(kv2, hh));
+    v3 p3 = add(p0, mul(v2, hh));
+    float r2c = dot(p3, p3), rc, yc, hc;
+    const unsigned long long sc = stage_radius_yh<1>(r2c, yb, hb, rc, yc, hc);
+    v3 kv3 = geodesic_acc_ng<SPIN>(p3, v3_, drag_c, r2c, rc, yc, sc);
+    v3 v4 = add(v0, mul(kv3, h));
+    v3 p4 = add(p0, mul(v3_, h));
+    float r2d = dot(p4, p4), rd, yd, hd;
+    const unsigned long long sd = stage_radius_yh<2>(r2d, yc, hc, rd, yd, hd);
+    v3 kv4 = geodesic_acc_ng<SPIN>(p4, v4, drag_c, r2d, rd, yd, sd);
+    v3 kv_sum, kp_sum;
+    kv_sum.x = kv1.x + __builtin_fmaf(2.0f, kv2.x, __builtin_fmaf(2.0f, kv3.x, kv4.x));
+    kv_sum.y = kv1.y + __builtin_fmaf(2.0f, kv2.y, __builtin_fmaf(2.0f, kv3.y, kv4.y));
+    kv_sum.z = kv1.z + __builtin_fmaf(2.0f, kv2.z, __builtin_fmaf(2.0f, kv3.z, kv4.z));
+    kp_sum.x = v0.x + __builtin_fmaf(2.0f, v2.x, __builtin_fmaf(2.0f, v3_.x, v4.x));
+    kp_sum.y = v0.y + __builtin_fmaf(2.0f, v2.y, __builtin_fmaf(2.0f, v3_.y, v4.y));
+    kp_sum.z = v0.z + __builtin_fmaf(2.0f, v2.z, __builtin_fmaf(2.0f, v3_.z, v4.z));
+    v = add(v0, mul(kv_sum, h6));
+    p = add(p0, mul(kp_sum, h6));
+    y_next = yd;
+    h_next = hd;
+}
+
+/*
  * FAST arithmetic mode (rrt_params.arith_mode = RRT_ARITH_FAST; NOT the parity path).
  * Same equations (geodesics.h:30-45, integrators.h:23-59) evaluated the way a GPU compiler with
  * contraction would: fused multiply-adds, 1/r from v_rsq_f32 (1 ulp) instead of correctly rounded

@@ -392,13 +392,26 @@ __device__ __forceinline__ void zone_step(bool near_bh, bool in_disk, float& h, 
     h6 = near_bh ? kHNear / 6.0f : (in_disk ? kHDisk / 6.0f : kHVac / 6.0f);
 }
 
+/* Round 3: RRT_MARCH_V2 = the lean RK4 step (rrt_device.h: integrate_rk4_lean) and, with
+ * RRT_VACUUM_PATH, a wave-uniform vacuum step.  -DRRT_MARCH_V2=0 builds round 2's loop (A/B: profiles/README.md). */
+#ifndef RRT_MARCH_V2
+#define RRT_MARCH_V2 1
+#endif
+#ifndef RRT_VACUUM_PATH
+#define RRT_VACUUM_PATH 1
+#endif
+/* r >= kVacuumR rules out the horizon test (r < 2.02) and every zone of raymarcher.cu:56-58 (near_bh r < 18, disk zone
+ * r < 30, cloud zone r < 25): the step is h = STEP_SIZE_M with no media sample.  About nine steps in ten of the bench
+ * frame are taken by wavefronts whose 64 rays are all out there. */
+constexpr float kVacuumR = kDiskOut + 5.0f;
+
 /* The whole march of one ray with the media sampled in line: raymarcher.cu:41-121.
  * MEDIA: 0 = densities read 0 ("skybox only"), 1 = full media, 2 = full media with the lattice-hash tables.
  * `i`: in = first step (0, or where a resumed ray stopped), out = steps taken.  When every lane starts at the
  * same step the loop counter stays in a scalar register; the per-ray count is written once, at the exit. */
 template <bool SPIN, int MEDIA, bool FAST>
-__device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel, Radiance& acc, bool& hit, int& i,
-                                             unsigned* oob) {
+__device__ __forceinline__ void march_inline_v1(const FrameArgs& a, v3& p, v3& vel, Radiance& acc, bool& hit, int& i,
+                                                unsigned* oob) {
     int steps = i > a.max_steps ? i : a.max_steps;      /* if the loop runs out */
     float y_seed = 0.0f;                                /* 1/r estimate for the next step's radius; 0: none yet */
     for (int k = i; k < a.max_steps; ++k) {
@@ -424,6 +437,49 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
         if (r > 250.0f && dot(rel_p, vel) > 0.0f) { steps = k + 1; break; }
     }
     i = steps;
+}
+
+template <bool SPIN, int MEDIA, bool FAST>
+__device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel, Radiance& acc, bool& hit, int& i,
+                                             unsigned* oob) {
+    if constexpr (FAST || !RRT_MARCH_V2) {
+        march_inline_v1<SPIN, MEDIA, FAST>(a, p, vel, acc, hit, i, oob);
+    } else {
+        int steps = i > a.max_steps ? i : a.max_steps;  /* if the loop runs out */
+        float ys = 0.0f, hs = 0.0f;                     /* (1/r, 1/(2r)) estimate for the next loop-top radius; 0: none yet */
+        for (int k = i; k < a.max_steps; ++k) {
+            const v3 rel_p = p;                         /* p - MASS_POS, MASS_POS = 0 */
+            const float r2 = dot(rel_p, rel_p);
+            float r, y, hy;
+            const bool rejected = sqrt_seeded_yh<1>(r2, ys, hs, r, y, hy);
+            /* wave-uniform: every live lane holds an accepted radius >= kVacuumR (two compares, scalar logic) */
+            const unsigned long long rej_mask = __builtin_amdgcn_ballot_w64(rejected);
+            const bool vacuum = RRT_VACUUM_PATH && (rej_mask | __builtin_amdgcn_ballot_w64(!(r >= kVacuumR))) == 0ull;
+            if (!vacuum && rej_mask != 0ull) {
+                bool small;                             /* r < 1 ends the ray at the horizon test below */
+                if (rejected) radius_fallback(r2, r, y, hy, small);
+            }
+            if (r < kEventHorizon * 1.01f) { hit = true; acc.t = 0.0f; steps = k; break; }
+
+            if (vacuum) {
+                integrate_rk4_lean<SPIN, true>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, y, hy, ys, hs);
+            } else {
+                const bool near_bh = r < 18.0f;
+                const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
+                const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
+                float h, hh, h6;
+                zone_step(near_bh, in_disk, h, hh, h6);
+                integrate_rk4_lean<SPIN, false>(p, vel, h, hh, h6, a.drag_c, r2, r, y, hy, ys, hs);
+                if (MEDIA != 0 && (in_disk || in_cloud)) {
+                    float d_disk, d_cloud;
+                    media_densities<MEDIA == 2>(rel_p, a.time, in_disk, in_cloud, a.lut_acc, a.lut_dust, oob, d_disk, d_cloud);
+                    accumulate_sample(acc, d_disk, d_cloud, rel_p, r, vel, h, a.spin);
+                }
+            }
+            if (r > 250.0f && dot(rel_p, vel) > 0.0f) { steps = k + 1; break; }     /* raymarcher.cu:120 */
+        }
+        i = steps;
+    }
 }
 
 /* Workgroup geometry of the per-ray kernels.  A wavefront covers a compact kTileW x kTileH pixel tile (8x8
@@ -527,19 +583,33 @@ __global__ __launch_bounds__(kWGThreads) __attribute__((amdgpu_num_sgpr(80))) vo
     unsigned used = kBlockRows;                                   /* rows used in the current block */
     bool overflow = false;                                        /* this lane stopped because the pool is full */
 
-    float y_seed = 0.0f;
+    constexpr bool LEAN = !FAST && RRT_MARCH_V2;               /* round 3's step (march_inline has the notes) */
+    float y_seed = 0.0f, h_seed = 0.0f;
     for (; i < a.max_steps; ++i) {
         const v3 rel_p = p;
-        float r2, r, yv;
-        if (RRT_SEEDED_SQRT) march_radius_seeded<FAST>(rel_p, y_seed, r2, r, yv);
+        float r2, r, yv, hv = 0.0f;
+        bool vacuum = false;
+        if constexpr (LEAN) {
+            r2 = dot(rel_p, rel_p);
+            const bool rejected = sqrt_seeded_yh<1>(r2, y_seed, h_seed, r, yv, hv);
+            const unsigned long long rej_mask = __builtin_amdgcn_ballot_w64(rejected);
+            vacuum = RRT_VACUUM_PATH && (rej_mask | __builtin_amdgcn_ballot_w64(!(r >= kVacuumR))) == 0ull;
+            if (!vacuum && rej_mask != 0ull) {
+                bool small;
+                if (rejected) radius_fallback(r2, r, yv, hv, small);
+            }
+        } else if (RRT_SEEDED_SQRT) march_radius_seeded<FAST>(rel_p, y_seed, r2, r, yv);
         else march_radius<FAST>(rel_p, r2, r, yv);
         if (r < kEventHorizon * 1.01f) { hit = true; break; }
 
-        const bool near_bh = r < 18.0f;
-        const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
-        const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
-        float h, hh, h6;
-        zone_step(near_bh, in_disk, h, hh, h6);
+        bool in_disk = false, in_cloud = false;
+        float h = kHVac, hh = 0.5f * kHVac, h6 = kHVac / 6.0f;
+        if (!vacuum) {                                             /* wave-uniform */
+            const bool near_bh = r < 18.0f;
+            in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
+            in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
+            zone_step(near_bh, in_disk, h, hh, h6);
+        }
 
         /* Both density functions return 0 unless the cylindrical radius rc = sqrtf(x*x + 0*0 + z*z) is in
          * [ISCO, DISK_OUT] (densities.h:21-22, :70-71); only those steps need a sample.  rc comes from
@@ -549,7 +619,7 @@ __global__ __launch_bounds__(kWGThreads) __attribute__((amdgpu_num_sgpr(80))) vo
         unsigned long long need_mask = 0ull;
         bool need = false;
         float* row_f = nullptr;
-        if (__any(in_disk || in_cloud)) {
+        if (!vacuum && __any(in_disk || in_cloud)) {
             if (in_disk || in_cloud) {
                 const float rc2 = rel_p.x * rel_p.x + 0.0f * 0.0f + rel_p.z * rel_p.z;
                 float rc, rci;
@@ -609,9 +679,12 @@ __global__ __launch_bounds__(kWGThreads) __attribute__((amdgpu_num_sgpr(80))) vo
             ++used;
         }
 
-        march_step<SPIN, FAST>(p, vel, h, hh, h6, a.drag_c, r2, r, yv, y_seed);
+        if constexpr (LEAN) {
+            if (vacuum) integrate_rk4_lean<SPIN, true>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, yv, hv, y_seed, h_seed);
+            else integrate_rk4_lean<SPIN, false>(p, vel, h, hh, h6, a.drag_c, r2, r, yv, hv, y_seed, h_seed);
+        } else march_step<SPIN, FAST>(p, vel, h, hh, h6, a.drag_c, r2, r, yv, y_seed);
 
-        if (need) {                                                /* pre-step position, post-step velocity */
+        if (!vacuum && need) {                                                /* pre-step position, post-step velocity */
             row_f[0] = rel_p.x; row_f[64] = rel_p.y; row_f[128] = rel_p.z;
             row_f[192] = vel.x; row_f[256] = vel.y; row_f[320] = vel.z;
         }
@@ -961,8 +1034,19 @@ __global__ void k_selfcheck_sqrt_seeded(uint32_t lo, uint32_t hi, unsigned long 
                 }
                 const float seed = y_exact * (1.0f + (float)sgn * delta);
                 float r1, y1, r2, y2;
+#if RRT_MARCH_V2
+                /* the form the march uses since round 3: (y, y/2) handed on, acceptance on the FIRST residual */
+                float h1, h2;
+                if (!sqrt_seeded_yh<1>(x, seed, 0.5f * seed, r1, y1, h1)) { ++accepted; if (rrt_f2u(r1) != rrt_f2u(want) || y1 != h1 + h1) { ++bad; counters[1] = b; counters[2] = rrt_f2u(seed); } }
+                if (!sqrt_seeded_yh<2>(x, seed, 0.5f * seed, r2, y2, h2)) { ++accepted; if (rrt_f2u(r2) != rrt_f2u(want) || y2 != h2 + h2) { ++bad; counters[1] = b; counters[2] = rrt_f2u(seed); } }
+                /* a seed of twice the reciprocal root (x*y0^2 = 4) converges to MINUS the root: it must be rejected */
+                if (k == 0 && sgn > 0) {
+                    if (!sqrt_seeded_yh<2>(x, 2.0f * y_exact, y_exact, r2, y2, h2) || !sqrt_seeded_yh<1>(x, 2.0f * y_exact, y_exact, r1, y1, h1)) { ++bad; counters[1] = b; counters[2] = 4; }
+                }
+#else
                 if (sqrt_seeded<1>(x, seed, r1, y1)) { ++accepted; if (rrt_f2u(r1) != rrt_f2u(want)) { ++bad; counters[1] = b; counters[2] = rrt_f2u(seed); } }
                 if (sqrt_seeded<2>(x, seed, r2, y2)) { ++accepted; if (rrt_f2u(r2) != rrt_f2u(want)) { ++bad; counters[1] = b; counters[2] = rrt_f2u(seed); } }
+#endif
             }
         }
     }

@@ -10,11 +10,11 @@ stays clear:
                      compiled by g++, see oracle/ref_units.cpp).  These pin the
                      oracle restatement to the reference, bit for bit.
   camera_ref.npz     catmull_rom / lerp_angle samples and the three keyframe
-                     tables from the reference's src/camera_paths.cpp.
-  camera_states_restatement.npz
-                     camera bases along the three paths at recording frames 1/75/150/
-                     225/300, from the build's C++ restatement of main.cpp:141-203
-                     (main.cpp is unbuildable here): regression pins only.
+                     tables from the reference's src/camera_paths.cpp, and CameraState
+                     outputs of the reference's own CameraController::getCUDAStateFrom /
+                     PathController::getInterpolatedState (src/main.cpp:125-220 piped into
+                     g++, oracle/ref_main_camera_pre.h): recording frames 1/75/150/225/300
+                     of each path, a sweep of path times, random (pos, yaw, pitch).
   frames_ref.npz     small frames rendered by the REFERENCE's own raymarch_kernel body
                      (/root/reference/src/raymarcher.cu:15-174 compiled by g++ where it lies,
                      oracle/ref_frames.cpp + ref_frames_pre.h -> oracle/_ref/libref_frames.so):
@@ -124,19 +124,29 @@ def make_camera():
     for idx, (name, keys) in enumerate(rc.paths()):
         out[f"path{idx}_keys"] = keys
         out[f"path{idx}_name"] = np.frombuffer(name.encode(), np.uint8)
+    # CameraState of the reference's OWN main.cpp code (CameraController::getCUDAStateFrom :141-167,
+    # PathController::getInterpolatedState / start / update :176-212, piped into g++: oracle/Makefile):
+    #  - recording frames {1, 75, 150, 225, 300} of each path under the recording clock, with the
+    #    controller's own float path time;
+    #  - a dense sweep of explicit path times over each path (before the first key, on keys, past the end);
+    #  - 256 random (pos, yaw, pitch) through getCUDAStateFrom, and the default free camera (main.cpp:127-130).
+    for idx in range(len(rc.paths())):
+        for k in (1, 75, 150, 225, 300):
+            st, pt = rc.path_state_at_frame(idx, k)
+            out[f"path{idx}_frame{k}"] = st
+            out[f"path{idx}_frame{k}_time"] = np.float32(pt)
+        keys = rc.paths()[idx][1]
+        ts = np.concatenate([np.float32([-1.0, 0.0]), keys[:, 0], rng.uniform(0, float(keys[-1, 0]) + 2.0, 96).astype(np.float32)])
+        out[f"path{idx}_sweep_t"] = ts.astype(np.float32)
+        out[f"path{idx}_sweep_state"] = np.stack([rc.path_state_at(idx, t) for t in ts])
+    cpos = rng.uniform(-80, 80, (256, 3)).astype(np.float32)
+    cyaw = rng.uniform(-540, 540, 256).astype(np.float32)
+    cpitch = rng.uniform(-89, 89, 256).astype(np.float32)
+    out["cam_pos"], out["cam_yaw"], out["cam_pitch"] = cpos, cyaw, cpitch
+    out["cam_state"] = np.stack([rc.state_from(cpos[i], cyaw[i], cpitch[i]) for i in range(256)])
+    out["default_camera"] = rc.default_camera()
     np.savez_compressed(os.path.join(HERE, "camera_ref.npz"), **out)
     print("camera_ref.npz:", len(out), "arrays")
-    # Camera states along the three paths at recording frames {1, 75, 150, 225, 300} (dt = 1/24 accumulated in
-    # binary32).  getInterpolatedState / getCUDAStateFrom live in src/main.cpp, which cannot be built
-    # here, so these come from the build's own C++ restatement (rrt_path_camera_at): regression pins only.
-    from relativisticraytracer_amd import camera_paths as cp
-    states = {}
-    for idx, path in enumerate(cp.paths()):
-        for k in (1, 75, 150, 225, 300):
-            _, pt = cp.recording_clock(k)
-            states[f"path{idx}_frame{k}"] = path.camera_at(pt).as_array()
-    np.savez_compressed(os.path.join(HERE, "camera_states_restatement.npz"), **states)
-    print("camera_states_restatement.npz:", len(states), "arrays")
 
 
 # frame cases: name -> (w, h, spin, volumetrics, camera(pos,yaw,pitch), time, effects overrides)

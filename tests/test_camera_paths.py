@@ -75,15 +75,27 @@ def test_path_argument_errors():
     assert lib.rrt_recording_clock(-1, 24, None, None) == 1
 
 
-def test_path_camera_states_regression():
-    """Camera states at recording frames 1/75/150/225/300 of each path (restatement-generated fixture)."""
-    import os
+def test_path_camera_states_equal_the_reference_main_cpp(camera_ref):
+    """f2 pinned to the reference: rrt_path_camera_at / rrt_camera_from_angles / rrt_recording_clock against the
+    CameraState outputs of the reference's OWN CameraController::getCUDAStateFrom (main.cpp:141-167) and
+    PathController::getInterpolatedState under the recording clock (:176-212, :511-516) -- that line range of
+    src/main.cpp piped into g++ (oracle/Makefile, oracle/ref_main_camera_pre.h) -- bit for bit:
+    recording frames {1, 75, 150, 225, 300} of the three paths, a sweep of path times (before the
+    first key, on every key, past the end), and 256 random (pos, yaw, pitch)."""
+    import relativisticraytracer_amd as rrt
     from relativisticraytracer_amd import camera_paths as cp
-    gold = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "camera_states_restatement.npz")))
     for idx, path in enumerate(cp.paths()):
         for k in (1, 75, 150, 225, 300):
             _, pt = cp.recording_clock(k)
+            assert np.float32(pt) == camera_ref[f"path{idx}_frame{k}_time"], (idx, k)      # the controller's own accumulator
             got = path.camera_at(pt).as_array()
-            assert np.array_equal(got, gold[f"path{idx}_frame{k}"]), (idx, k)
-            f, r, u = got[1], got[2], got[3]
-            assert abs(np.dot(f, r)) < 1e-6 and abs(np.dot(f, u)) < 1e-6 and abs(np.linalg.norm(f) - 1) < 1e-6
+            assert same_bits(got, camera_ref[f"path{idx}_frame{k}"]), (idx, k)
+        ts = camera_ref[f"path{idx}_sweep_t"]
+        got = np.stack([path.camera_at(float(t)).as_array() for t in ts])
+        assert same_bits(got, camera_ref[f"path{idx}_sweep_state"]), idx
+    pos, yaw, pitch = camera_ref["cam_pos"], camera_ref["cam_yaw"], camera_ref["cam_pitch"]
+    got = np.stack([rrt.CameraState.from_angles(pos[i], yaw[i], pitch[i]).as_array() for i in range(len(yaw))])
+    assert same_bits(got, camera_ref["cam_state"])
+    d = camera_ref["default_camera"]                 # main.cpp:127-130
+    assert same_bits(rrt.CameraState.default().as_array(), rrt.CameraState.from_angles(d[:3], d[3], d[4]).as_array())
+    assert np.array_equal(d, np.float32([0.0, 10.0, -60.0, 0.0, -10.0]))
