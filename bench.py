@@ -48,6 +48,33 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+CPU_TARGET_S = 12.0       # wall seconds the timed CPU leg should last (>= 10 s: start-up and imbalance no longer show)
+
+
+def cpu_sample_stride(width, height, spin, sky):
+    """Stride of the CPU baseline's pixel sample, sized so that the leg runs about CPU_TARGET_S on THIS host: a short
+    probe (every 16th pixel, a few tenths of a second on a 128-thread host) measures the rate, then
+    stride = floor(sqrt(pixels / (rate * target))), at least 1 (= the whole frame).  Round 2 sampled every 8th pixel:
+    0.9 s on 128 threads, i.e. two rows per thread -- start-up and imbalance dominated (VERDICT r02 weak #5)."""
+    import math
+    from oracle import pyoracle as po
+    import relativisticraytracer_amd as rrt
+    po.build()
+    po.use_native_build()
+    a = rrt.CameraState.default().as_array()
+    cam = po.camera(a[0], a[1], a[2], a[3])
+    probe = 16
+    t0 = time.perf_counter()
+    if po.ref_frames_available():
+        po.ref_render(a, po.default_effects(), spin, 1, 1.0, width, height, sky, n_threads=po.max_threads(), stride=(probe, probe))
+    else:
+        po.render(cam, po.default_effects(), po.default_params(spin=spin), 1.0, width, height, sky, stride=(probe, probe),
+                  want=("diag",), n_threads=po.max_threads())
+    dt = max(time.perf_counter() - t0, 1e-3)
+    rate = (math.ceil(width / probe) * math.ceil(height / probe)) / dt
+    return max(1, int(math.floor(math.sqrt(width * height / max(rate * CPU_TARGET_S, 1.0)))))
+
+
 def cpu_baseline(width, height, spin, stride, sky, cam_arr=None, time_=1.0):
     """Oracle (OpenMP, libm) on pixels (x, y) with x % stride == y % stride == 0 of the same frame."""
     import numpy as np
@@ -75,11 +102,12 @@ def cpu_baseline(width, height, spin, stride, sky, cam_arr=None, time_=1.0):
     n = int(sel.sum())
     means = {k: float(r[k][sel].mean()) for k in ("steps", "n_noise", "n_dens", "n_samples")}
     port = {"value": n / dt / 1e6, "unit": "Mrays/s", "cores": nthreads, "kind": "port",
+            "rays_per_s_per_thread": round(n / dt / nthreads, 1), "sample_rays": n, "wall_s": round(dt, 2),
             "cpu_model": cpu_model,
             "build": "gcc -O3 -march=native -ffp-contract=off -fopenmp" if native else
                      "gcc -O2 -mfma -ffp-contract=off -fopenmp",
             "sample": f"every {stride}th pixel in x and y of the same {width}x{height} frame "
-                      f"({n} rays, {dt:.1f} s wall, oracle/rrt_oracle.c, libm math, OpenMP dynamic rows)"}
+                      f"({n} rays, {dt:.1f} s wall, oracle/rrt_oracle.c, libm math, OpenMP dynamic over row segments of 128 samples)"}
     if not po.ref_frames_available():
         return port, means
     # oracle/_ref/libref_frames.so = the REFERENCE's own raymarch_kernel body (and headers), compiled by g++ in the
@@ -91,12 +119,13 @@ def cpu_baseline(width, height, spin, stride, sky, cam_arr=None, time_=1.0):
     dtr = time.perf_counter() - t0
     same_steps = bool(np.array_equal(rr["steps"][sel], r["steps"][sel]))
     return {"value": n / dtr / 1e6, "unit": "Mrays/s", "cores": nthreads, "kind": "reference",
+            "rays_per_s_per_thread": round(n / dtr / nthreads, 1), "sample_rays": n, "wall_s": round(dtr, 2),
             "cpu_model": cpu_model,
             "build": "g++ -O2 -ffp-contract=off -fopenmp on /root/reference/src/raymarcher.cu:15-174 + include/*.h "
                      "(oracle/Makefile ref; harness: launch indices, tex2D = the documented sky filter)",
             "sample": f"every {stride}th pixel in x and y of the same {width}x{height} frame "
                       f"({n} rays, {dtr:.1f} s wall, the reference's raymarch_kernel called per pixel, glibc math, "
-                      f"OpenMP dynamic rows)",
+                      f"OpenMP dynamic over row segments of 128 samples; stride sized for ~{CPU_TARGET_S:.0f} s on this host)",
             "step_counts_equal_port": same_steps, "port": port}, means
 
 
@@ -130,7 +159,8 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--spin", type=float, default=0.9)
     ap.add_argument("--tile-rows", type=int, default=16)
-    ap.add_argument("--cpu-stride", type=int, default=8, help="CPU baseline sample stride (0 = skip)")
+    ap.add_argument("--cpu-stride", type=int, default=-1,
+                    help="CPU baseline sample stride: -1 (default) = sized so that the leg runs ~12 s on this host, 0 = skip")
     ap.add_argument("--no-fast", action="store_true", help="skip the informational RRT_ARITH_FAST leg")
     ap.add_argument("--no-noise-table", action="store_true", help="hash every noise3D corner arithmetically (no lattice tables)")
     ap.add_argument("--no-heavy", action="store_true", help="skip the informational heavy-view leg")
@@ -215,7 +245,7 @@ def main():
     # N > 1: the following frames are rendered (on their own streams) while frame k is gathered and assembled; the
     # frames still in flight are flushed (gathered + assembled) inside the timed region, so K timed steps deliver K frames.
     fs = sharding.FrameSharder(w, h, R, rank, world, dev, render, assemble, assemble_all=assemble_all,
-                               pipeline=n_slots if pipeline else False)
+                               pipeline=n_slots if pipeline else False, timing=world > 1)
 
     # Untimed one-off setup, so that even --warmup 0 times steady-state steps: load the code object with a
     # tiny launch, and bring up the RCCL communicator / its peer-to-peer channels with one small collective
@@ -251,6 +281,54 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev[args.warmup:]]
+
+    # N > 1, so that the first real multi-GPU run explains its own efficiency:
+    #  - every rank's own phase latencies (render | gather = queueing + waiting for the slowest rank + transfer |
+    #    assemble), from device events on the stream each step ran on, all-gathered to rank 0;
+    #  - the same K frames ONE AT A TIME (no frames in flight): latency-bound strong scaling, reported next to the
+    #    pipelined `value` (throughput with frames in flight, frames arrive n-1 steps late).
+    phases, one_at_a_time = None, None
+    if world > 1:
+        mine = fs.phase_times(skip=args.warmup) or {"render": 0.0, "gather": 0.0, "assemble": 0.0, "steps": 0}
+        allp = [None] * world
+        dist.all_gather_object(allp, {k: round(float(v), 4) for k, v in mine.items()})
+        phases = {"per_rank_render_ms": [p["render"] for p in allp], "per_rank_gather_ms": [p["gather"] for p in allp],
+                  "rank0_assemble_ms": allp[0]["assemble"],
+                  "render_balance_min_over_max": round(min(p["render"] for p in allp) / max(max(p["render"] for p in allp), 1e-9), 4),
+                  "note": "device-event latencies of each frame's own phases on its stream; with several frames in flight "
+                          "consecutive frames overlap, so these do not add up to ms_per_step"}
+        if pipeline:
+            it1 = {"i": 0}
+            ev1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps + 1)]
+
+            def render1(buf, slot):
+                e0, e1 = ev1[it1["i"]]
+                e0.record()
+                rrt.launch_raymarch_tiles(buf, w, h, R, rank, world, 1.0, cam, tex, fx, prms[0])
+                e1.record()
+
+            fs1 = sharding.FrameSharder(w, h, R, rank, world, dev, render1, assemble, assemble_all=assemble_all,
+                                        pipeline=False, timing=True)
+            fs1.step(); it1["i"] += 1
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                fs1.step(); it1["i"] += 1
+            barrier()
+            dt1 = time.perf_counter() - t1
+            tt = torch.tensor([dt1], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt1 = float(tt.item())
+            p1 = fs1.phase_times(skip=1) or {"render": 0.0, "gather": 0.0, "assemble": 0.0}
+            allp1 = [None] * world
+            dist.all_gather_object(allp1, {k: round(float(v), 4) for k, v in p1.items()})
+            one_at_a_time = {"ms_per_step": round(dt1 / args.steps * 1e3, 3),
+                             "value": round(w * h * args.steps / dt1 / 1e6, 3), "unit": "Mrays/s",
+                             "per_rank_render_ms": [p["render"] for p in allp1],
+                             "per_rank_gather_ms": [p["gather"] for p in allp1], "rank0_assemble_ms": allp1[0]["assemble"],
+                             "note": "the same frames with --frames-in-flight 1: each frame rendered, gathered and assembled "
+                                     "before the next starts (latency-bound strong scaling); step = max over ranks of render "
+                                     "+ gather + assemble"}
 
     # Informational second leg (single GPU only): the same frame in RRT_ARITH_FAST (FMA + rsq in the
     # integrator).  It is NOT the parity path and never `value`; its deviation from the strict frame
@@ -312,8 +390,9 @@ def main():
         my_rays = sharding.shard_rows(h, R, 0, world) * w
 
         cpu, means = (None, None)
-        if world == 1 and args.cpu_stride > 0:
-            cpu, means = cpu_baseline(w, h, args.spin, args.cpu_stride, sky_np)
+        if world == 1 and args.cpu_stride != 0:
+            stride = args.cpu_stride if args.cpu_stride > 0 else cpu_sample_stride(w, h, args.spin, sky_np)
+            cpu, means = cpu_baseline(w, h, args.spin, stride, sky_np)
         if means is None:   # per-ray work from a small oracle sample even when the baseline is skipped
             _, means = cpu_baseline(w, h, args.spin, 48, sky_np)
         opr = ops_per_ray(means["steps"], means["n_noise"], means["n_dens"], means["n_samples"])
@@ -334,7 +413,7 @@ def main():
                     traffic_note = "profiles/hbm_traffic.json is from another build or workload; not used"
             except Exception:
                 traffic = None
-        if heavy is not None and args.cpu_stride > 0:
+        if heavy is not None and args.cpu_stride != 0:
             # per-ray work of the heavy view from a small oracle sample (exact counts, like the headline's)
             _, hm = cpu_baseline(w, h, args.spin, 96, sky_np, cam_arr=rrt.CameraState.from_angles((4.2, 0.6, 4.2), -90.0, -5.7).as_array(),
                                  time_=14.0)
@@ -376,6 +455,12 @@ def main():
             "fast_mode": fast,
             "heavy_view": heavy,
         }
+        if world > 1:
+            line["multi_gpu"] = {"phases": phases, "one_frame_at_a_time": one_at_a_time,
+                                 "frames_in_flight": fs.n_slots,
+                                 "frames_in_flight_note": "default 3: chosen on ONE GPU rendering a single rank's share "
+                                                          "(profiles/r02_frames_in_flight.txt); provisional until a run on >= 2 GPUs"}
+        
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

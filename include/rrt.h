@@ -156,13 +156,35 @@ int rrt_workspace_read(int id, size_t offset, size_t bytes, void* host_dst);
 
 /* ---- lattice-hash tables for the volumetric noise (rrt_params.noise_table): hash31 (math_utils.h:91-96) of
  *      every lattice point the low-octave noise3D calls of getAccretionDensity / getDustCloudDensity
- *      (densities.h:54, :95-128) can reach for 0 <= time <= t_max, computed once on the device by the same
- *      arithmetic.  Caller-owned like the sky; about 0.2 GB at t_max = 32 s (rrt_noise_table_plan tells).
- *      Any number of launches / streams may read one table concurrently. ---- */
-int rrt_noise_table_create(float t_max, int* out_id);
+ *      (densities.h:54, :95-128) can reach for t0 <= time <= t1, computed once on the device by the same
+ *      arithmetic (a few milliseconds).  Caller-owned like the sky and tied to the device it was created on; any
+ *      number of launches / streams of that device may read one table concurrently.  A launch whose `time` lies
+ *      outside the window renders with the arithmetic kernels: same bytes, slower.
+ *      Size: 0.49 GB for [0, 32 s] at full coverage.  It does not stay bounded as the window slides along the
+ *      reference's unbounded simTime (main.cpp:515): the dust coordinates shear with time * (10/rc)^1.5
+ *      (densities.h:88-93), so the z extent of the box grows like 0.75 t0 + (t1 - t0).  Hence two knobs: the window
+ *      and the coverage -- which call families are table-served; the finest ones dominate the volume:
+ *          RRT_TABLE_FULL      all table-served families
+ *          RRT_TABLE_COARSE    without the 4.41 and 4.0 cells-per-unit dust families (about 1/9 of the dust box)
+ *          RRT_TABLE_COARSEST  also without the 2.1 dust family and the finest accretion octave
+ *      and rrt_noise_table_fit_window(), the policy the headless drivers use: longest window from t_from, richest
+ *      coverage, within a byte budget (*bytes_out == 0: nothing fits, render without a table).
+ *      rrt_noise_table_plan*() is host arithmetic only and returns the same RRT_ERR_INVALID_ARGUMENT as create for a
+ *      box that cannot be addressed (>= 2^28 lattice points). ---- */
+enum { RRT_TABLE_FULL = 0, RRT_TABLE_COARSE = 1, RRT_TABLE_COARSEST = 2 };
+int rrt_noise_table_create(float t_max, int* out_id);                                  /* = window [0, t_max], full coverage */
+int rrt_noise_table_create_window(float t0, float t1, int coverage, int* out_id);
 int rrt_noise_table_destroy(int id);
 int rrt_noise_table_info(int id, float* t_max, size_t* bytes, int* boxes12);   /* boxes: x0,y0,z0,nx,ny,nz of the accretion and dust boxes */
-int rrt_noise_table_plan(float t_max, size_t* bytes, int* boxes12);            /* host arithmetic only */
+int rrt_noise_table_window(int id, float* t0, float* t1, int* coverage, int* device);
+int rrt_noise_table_plan(float t_max, size_t* bytes, int* boxes12);
+int rrt_noise_table_plan_window(float t0, float t1, int coverage, size_t* bytes, int* boxes12);
+int rrt_noise_table_fit_window(float t_from, float t_until, size_t budget_bytes, float* t1_out, int* coverage_out, size_t* bytes_out);
+
+/* Handles and devices: a sky, workspace or noise table belongs to the HIP device that was current when it was
+ * created (a borrowed sky: the device that owns the pointer), and a launch or copy that names it under another
+ * current device returns RRT_ERR_BAD_HANDLE.  Test hook: pretend `device` is current (< 0: ask HIP again). */
+int rrt_debug_fake_device(int device);
 
 /* ---- parameters of the reference-signature entry point launch_raymarch() (include/raymarcher.h), which has
  *      no argument for them: spin, max_steps, volumetrics, a workspace, a noise table ...  NULL restores the

@@ -64,18 +64,26 @@ extern "C" int ref_render_strided(const float* cam12, const int32_t* fx_flags4, 
     const cudaTextureObject_t tex = static_cast<cudaTextureObject_t>(reinterpret_cast<uintptr_t>(&img));
     if (n_threads <= 0) n_threads = omp_get_max_threads();
     const int rows = (height + sy - 1) / sy;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    /* tasks = (row, run of kTaskSamples samples), dynamic: the same granularity as the restatement's loop
+     * (oracle/rrt_oracle.c: rrto_render), so that bench.py's two CPU legs are scheduled alike */
+    const int kTaskSamples = 128;
+    const int nxs = (width + sx - 1) / sx, nbx = (nxs + kTaskSamples - 1) / kTaskSamples;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1) num_threads(n_threads)
     for (int j = 0; j < rows; ++j) {
-        const int y = j * sy;
-        ref_spin_value = spin;
-        ref_volumetrics = volumetrics;
-        blockDim = dim3(1, 1, 1);
-        threadIdx = make_uint3(0, 0, 0);
-        for (int x = 0; x < width; x += sx) {
-            blockIdx = make_uint3((unsigned)x, (unsigned)y, 0);
-            ref_step_count = 0;
-            raymarch_kernel(reinterpret_cast<uchar4*>(rgba8), width, height, time, cam, tex, fx);
-            if (steps) steps[(size_t)y * width + x] = ref_step_count;
+        for (int bx = 0; bx < nbx; ++bx) {
+            const int y = j * sy;
+            ref_spin_value = spin;                  /* thread-local harness state: set in every task */
+            ref_volumetrics = volumetrics;
+            blockDim = dim3(1, 1, 1);
+            threadIdx = make_uint3(0, 0, 0);
+            const int xa = bx * kTaskSamples * sx;
+            const int xb = xa + kTaskSamples * sx < width ? xa + kTaskSamples * sx : width;
+            for (int x = xa; x < xb; x += sx) {
+                blockIdx = make_uint3((unsigned)x, (unsigned)y, 0);
+                ref_step_count = 0;
+                raymarch_kernel(reinterpret_cast<uchar4*>(rgba8), width, height, time, cam, tex, fx);
+                if (steps) steps[(size_t)y * width + x] = ref_step_count;
+            }
         }
     }
     return 0;

@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <string.h>
+#define RRTO_TASK_SAMPLES 128      /* samples of one row per OpenMP task (rrto_render) */
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -608,10 +609,17 @@ int rrto_render_gates(const rrto_camera* cam, const rrto_effects* fx, const rrto
 #endif
     int ny = (y1 - y0 + sy - 1) / sy;
     const int nxs = (x1 - x0 + sx - 1) / sx;            /* gate logs are indexed by sample: jy*nxs + jx */
-#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    /* tasks = (row, run of RRTO_TASK_SAMPLES samples of that row), handed out dynamically: the rows through the
+     * hole and the disk cost several times the sky rows, and a whole row per task left the last threads of a
+     * 128-thread host idle for a sizeable part of a short run (bench.py's cpu_baseline leg) */
+    const int nbx = (nxs + RRTO_TASK_SAMPLES - 1) / RRTO_TASK_SAMPLES;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1) num_threads(n_threads)
     for (int jy = 0; jy < ny; ++jy) {
+      for (int bx = 0; bx < nbx; ++bx) {
         int y = y0 + jy * sy;
-        for (int x = x0; x < x1; x += sx) {
+        const int xa = x0 + bx * RRTO_TASK_SAMPLES * sx;
+        const int xb = (xa + RRTO_TASK_SAMPLES * sx < x1) ? xa + RRTO_TASK_SAMPLES * sx : x1;
+        for (int x = xa; x < xb; x += sx) {
             const size_t gi = (size_t)jy * nxs + (size_t)((x - x0) / sx);
             pixel_out o;
             size_t oi = (size_t)(height - 1 - y) * width + x;   /* raymarcher.cu:168 */
@@ -639,6 +647,7 @@ int rrto_render_gates(const rrto_camera* cam, const rrto_effects* fx, const rrto
                 if (diag->rad) memcpy(diag->rad + 4 * di, o.rad, 16);
             }
         }
+      }
     }
     return 0;
 }

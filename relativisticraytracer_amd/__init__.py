@@ -172,25 +172,54 @@ class Workspace:
             pass
 
 
-class NoiseTable:
-    """Caller-owned lattice-hash tables for the volumetric noise (RenderParams.noise_table = nt.id):
-    hash31 of every lattice point the low-octave noise3D calls can reach for 0 <= time <= t_max."""
+TABLE_FULL, TABLE_COARSE, TABLE_COARSEST = 0, 1, 2      # rrt.h: which noise call families a table serves
 
-    def __init__(self, t_max=32.0):
+
+class NoiseTable:
+    """Caller-owned lattice-hash tables for the volumetric noise (RenderParams.noise_table = nt.id): hash31 of every
+    lattice point the table-served noise3D calls can reach for t0 <= time <= t1 (NoiseTable(t_max) = [0, t_max]).
+    A launch whose time lies outside the window renders with the arithmetic kernels: same bytes, slower."""
+
+    def __init__(self, t_max=32.0, t0=0.0, coverage=TABLE_FULL):
         i = C.c_int(0)
-        _lib.check(_lib.load().rrt_noise_table_create(float(t_max), C.byref(i)), "rrt_noise_table_create")
-        self.id, self.t_max = i.value, float(t_max)
+        _lib.check(_lib.load().rrt_noise_table_create_window(float(t0), float(t_max), int(coverage), C.byref(i)),
+                   "rrt_noise_table_create_window")
+        self.id, self.t0, self.t1, self.t_max, self.coverage = i.value, float(t0), float(t_max), float(t_max), int(coverage)
+
+    @classmethod
+    def window(cls, t0, t1, coverage=TABLE_FULL):
+        return cls(t_max=t1, t0=t0, coverage=coverage)
+
+    def covers(self, time):
+        return self.t0 <= time <= self.t1
 
     def info(self):
         t, b, box = C.c_float(0), C.c_size_t(0), (C.c_int * 12)()
         _lib.check(_lib.load().rrt_noise_table_info(self.id, C.byref(t), C.byref(b), C.byref(box)), "rrt_noise_table_info")
-        return {"t_max": t.value, "bytes": b.value, "accretion_box": list(box[:6]), "dust_box": list(box[6:])}
+        t0, t1, cov, dev = C.c_float(0), C.c_float(0), C.c_int(0), C.c_int(0)
+        _lib.check(_lib.load().rrt_noise_table_window(self.id, C.byref(t0), C.byref(t1), C.byref(cov), C.byref(dev)),
+                   "rrt_noise_table_window")
+        return {"t_max": t.value, "t0": t0.value, "t1": t1.value, "coverage": cov.value, "device": dev.value,
+                "bytes": b.value, "accretion_box": list(box[:6]), "dust_box": list(box[6:])}
 
     @staticmethod
-    def plan(t_max):
+    def plan(t_max, t0=0.0, coverage=TABLE_FULL):
+        """Host arithmetic only: size and boxes of such a table; raises RRTError(INVALID_ARGUMENT) for a box that
+        create would refuse as well."""
         b, box = C.c_size_t(0), (C.c_int * 12)()
-        _lib.check(_lib.load().rrt_noise_table_plan(float(t_max), C.byref(b), C.byref(box)), "rrt_noise_table_plan")
-        return {"t_max": float(t_max), "bytes": b.value, "accretion_box": list(box[:6]), "dust_box": list(box[6:])}
+        _lib.check(_lib.load().rrt_noise_table_plan_window(float(t0), float(t_max), int(coverage), C.byref(b), C.byref(box)),
+                   "rrt_noise_table_plan_window")
+        return {"t_max": float(t_max), "t0": float(t0), "coverage": int(coverage), "bytes": b.value,
+                "accretion_box": list(box[:6]), "dust_box": list(box[6:])}
+
+    @staticmethod
+    def fit(t_from, t_until, budget_bytes):
+        """The frame drivers' policy (rrt_noise_table_fit_window): longest window from t_from, richest coverage,
+        within the byte budget -> (t1, coverage, bytes); bytes == 0: nothing fits."""
+        t1, cov, b = C.c_float(0), C.c_int(0), C.c_size_t(0)
+        _lib.check(_lib.load().rrt_noise_table_fit_window(float(t_from), float(t_until), int(budget_bytes), C.byref(t1),
+                                                          C.byref(cov), C.byref(b)), "rrt_noise_table_fit_window")
+        return t1.value, cov.value, b.value
 
     def destroy(self):
         if getattr(self, "id", 0):
@@ -202,6 +231,55 @@ class NoiseTable:
             self.destroy()
         except Exception:
             pass
+
+
+class NoiseWindows:
+    """What a frame loop does about the noise tables as the clock runs (src/main.cpp:515 lets simTime grow without
+    bound): keeps ONE table whose window holds the current frame time, within a byte budget; when the clock leaves
+    the window it builds the next one (a few milliseconds) -- after `sync()`, since frames in flight may still read
+    the old table.  `table_id(t)` is what goes into RenderParams.noise_table (0: this frame hashes arithmetically;
+    counted in `arith_frames`, never silent)."""
+
+    def __init__(self, t_end, budget_bytes, sync=None, enabled=True):
+        self.t_end, self.budget, self.sync, self.enabled = float(t_end), int(budget_bytes), sync, enabled
+        self.table = None
+        self.builds, self.table_frames, self.arith_frames, self.coarsest = 0, 0, 0, TABLE_FULL
+        self.peak_bytes = 0
+
+    def table_id(self, t):
+        if not self.enabled:
+            return 0
+        if self.table is None or not self.table.covers(t):
+            t1, cov, nbytes = NoiseTable.fit(t, max(t, self.t_end), self.budget)
+            if self.sync:
+                self.sync()
+            if self.table is not None:
+                self.table.destroy()
+                self.table = None
+            if nbytes:
+                try:
+                    self.table = NoiseTable.window(t, t1, cov)
+                    self.builds += 1
+                    self.coarsest = max(self.coarsest, cov)
+                    self.peak_bytes = max(self.peak_bytes, nbytes)
+                except _lib.RRTError as e:          # e.g. out of memory: warn once, carry on without
+                    if not getattr(self, "_warned", False):
+                        print(f"noise table [{t:g}, {t1:g}] not built ({e}); hashing arithmetically", flush=True)
+                        self._warned = True
+        if self.table is not None and self.table.covers(t):
+            self.table_frames += 1
+            return self.table.id
+        self.arith_frames += 1
+        return 0
+
+    def summary(self):
+        return {"builds": self.builds, "table_frames": self.table_frames, "arith_frames": self.arith_frames,
+                "coarsest_coverage": self.coarsest, "peak_bytes": self.peak_bytes, "budget_bytes": self.budget}
+
+    def close(self):
+        if self.table is not None:
+            self.table.destroy()
+            self.table = None
 
 
 def set_launch_defaults(params):

@@ -67,6 +67,11 @@ SYMBOLS = [
     ("rrt_noise_table_destroy", _i, [_i]),
     ("rrt_noise_table_info", _i, [_i, C.POINTER(_f), C.POINTER(C.c_size_t), C.POINTER(_i * 12)]),
     ("rrt_noise_table_plan", _i, [_f, C.POINTER(C.c_size_t), C.POINTER(_i * 12)]),
+    ("rrt_noise_table_create_window", _i, [_f, _f, _i, C.POINTER(_i)]),
+    ("rrt_noise_table_window", _i, [_i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_i), C.POINTER(_i)]),
+    ("rrt_noise_table_plan_window", _i, [_f, _f, _i, C.POINTER(C.c_size_t), C.POINTER(_i * 12)]),
+    ("rrt_noise_table_fit_window", _i, [_f, _f, C.c_size_t, C.POINTER(_f), C.POINTER(_i), C.POINTER(C.c_size_t)]),
+    ("rrt_debug_fake_device", _i, [_i]),
     ("rrt_set_launch_defaults", _i, [_prm]),
     ("rrt_get_launch_defaults", _i, [_prm]),
     ("rrt_launch_raymarch_compat", _i, [_vp, _i, _i, _f, C.POINTER(C.c_float * 12), _ull, _vp]),

@@ -160,6 +160,7 @@ struct NoiseLut {
     int origin;            /* (z0*ny + y0)*nx + x0 */
     int nx, nxy;
     unsigned last;         /* n_cells - nxy - 1 */
+    unsigned families;     /* which call families the box was sized for: ANDed into the callers' `from_table` words */
 };
 
 struct LutTap { float4 q0, q1; float ux, uy, uz; };
@@ -653,9 +654,16 @@ RRT_DEV float disk_temperature_t(float r) {
 }
 RRT_DEV float disk_temperature(float r) { return disk_temperature_t<false>(r); }
 
+/* RRT_PROBE (dev builds only, wrong pixels): bit 0 drops the accretion density, bit 1 the dust density, bit 2 the
+ * emission block, bit 3 replaces every noise3D by a cheap expression -- timing probes that apportion the media cost
+ * (tools/ab_views.py; profiles/README.md round 3). */
+#ifndef RRT_PROBE
+#define RRT_PROBE 0
+#endif
 /* one noise3D evaluation, from the table when the wave-uniform switch says so */
 template <bool LUT>
 RRT_DEV float noise3d_sel(v3 p, const NoiseLut& L, bool from_table, unsigned* oob) {
+    if (RRT_PROBE & 8) return 0.45f + 0.01f * p.x;
     if (LUT && from_table) return noise3d_lut(L, p, oob);
     return noise3d(p);
 }
@@ -666,6 +674,7 @@ RRT_DEV float noise3d_sel(v3 p, const NoiseLut& L, bool from_table, unsigned* oo
 #define RRT_LUT_PAIRS 1
 #endif
 RRT_DEV void noise3d_lut_pair(const NoiseLut& L, v3 p0, v3 p1, unsigned* oob, float& n0, float& n1) {
+    if (RRT_PROBE & 8) { n0 = 0.45f + 0.01f * p0.x; n1 = 0.45f + 0.01f * p1.x; return; }
     const LutTap a = lut_fetch(L, p0, oob);
     const LutTap b = lut_fetch(L, p1, oob);
     n0 = lut_blend(a);
@@ -778,6 +787,7 @@ RRT_DEV float accretion_density_at(v3 p, float time, DiskPoint& dp, const NoiseL
             if (lut_fits(sp, cells)) from_table |= 1u << o;
             cells *= 2.05f;
         }
+        from_table &= L.families;
     }
     float n = 0.0f, amp = 0.5f;                         /* fbm(at, 5), math_utils.h:112-121 */
 #pragma unroll 1
@@ -843,6 +853,7 @@ RRT_DEV float dust_density_at(v3 p, float time, DiskPoint& dp, const NoiseLut& L
             cells *= 2.1f;
         }
         if (kLutDetail && lut_fits(sp, 4.0f)) from_table |= 256u;             /* the detail fbm's second octave (8.2 cells per unit) is never coherent */
+        from_table &= L.families;
     }
 
     /* first warp, :95-99: fbm(c, 2), fbm(c + (1,2,3), 2), fbm(c + (4,5,6), 2) with c = sc*0.15
@@ -912,8 +923,8 @@ RRT_DEV void media_densities(v3 p, float time, bool in_disk, bool in_cloud, cons
     d_disk = 0.0f; d_cloud = 0.0f;
     DiskPoint dp;
     if (!disk_point<true>(p, dp)) return;
-    if (in_disk) d_disk = accretion_density_at<true, LUT>(p, time, dp, lut_acc, oob);
-    if (in_cloud) d_cloud = dust_density_at<LUT, true>(p, time, dp, lut_dust, oob);
+    if (in_disk && !(RRT_PROBE & 1)) d_disk = accretion_density_at<true, LUT>(p, time, dp, lut_acc, oob);
+    if (in_cloud && !(RRT_PROBE & 2)) d_cloud = dust_density_at<LUT, true>(p, time, dp, lut_dust, oob);
 }
 
 /* ---- radiative transfer of one in-zone sample, raymarcher.cu:67-117 ---- */
@@ -926,6 +937,7 @@ RRT_DEV bool sample_emission(float d_disk, float d_cloud, v3 rel_p, float r, v3 
                              float& ex, float& ey, float& ez, float& step_trans) {
     const bool disk_on = d_disk > 0.001f, dust_on = d_cloud > 0.001f;
     if (!(disk_on || dust_on)) return false;
+    if (RRT_PROBE & 4) { ex = d_disk; ey = d_cloud; ez = 0.f; step_trans = 0.99f; return true; }
     /* a density above the gate means the cylindrical radius is in [10, 25] and the sample inside a zone, so
      * r in [10, 30): the tame range of the lean divisions / square roots (their guards fall back otherwise) */
     ex = 0.f; ey = 0.f; ez = 0.f;

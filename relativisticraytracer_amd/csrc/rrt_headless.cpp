@@ -5,7 +5,12 @@
 // (captureFrame, :85-97 -- here a raw RGBA stream, the bytes the reference pipes into ffmpeg).
 //
 //   rrt_headless --width 1000 --height 700 --frames 24 --path 0 --spin 0.9 --out frames.rgba [--sky-seed 1]
-//                [--gpus N] [--tile-rows 16] [--workspace-gib G] [--noise-table-tmax T | --no-noise-table]
+//                [--gpus N] [--tile-rows 16] [--workspace-gib G] [--noise-table-gib B | --no-noise-table]
+//
+// Noise tables: the reference's simTime runs without bound (main.cpp:515) and a table's size grows with the times
+// it covers, so each device keeps ONE table over a window of the clock that fits --noise-table-gib (default 2;
+// rrt_noise_table_fit_window picks window and coverage) and rebuilds it -- milliseconds -- when the clock leaves the
+// window.  Frames that had to render without a table are counted in the summary line, never silent.
 //
 // Multi-GPU (the reference is single-GPU): ONE process drives N devices.  ncclCommInitAll
 // gives one RCCL communicator per device; image tile t (rows [16t, 16t+16)) belongs to device t mod N; every
@@ -82,6 +87,7 @@ struct Device {                // everything one GPU owns
     int id = 0;
     rrt_sky_t sky = 0;
     int noise_table = 0;
+    float table_t0 = 0.0f, table_t1 = -1.0f;      // window of noise_table (empty: none yet)
     int pool[kMaxSlots] = {};
     hipStream_t stream[kMaxSlots] = {};
     void* tiles[kMaxSlots] = {};                  // this device's shard of a frame
@@ -97,7 +103,8 @@ int main(int argc, char** argv) {
     int kSlots = 3;                // frames in flight: frame k renders on stream k mod kSlots while its predecessors are
                                    // gathered / assembled / copied out (a rank's share of a frame is only a few rounds of
                                    // wavefronts; 3 measured best at 8 shards of a 4K frame: profiles/r02_frames_in_flight.txt)
-    float spin = 0.0f, table_tmax = -1.0f;
+    float spin = 0.0f;
+    double table_gib = 2.0;
     std::string out_path;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -107,7 +114,7 @@ int main(int argc, char** argv) {
         else if (a == "--gpus") val(gpus); else if (a == "--tile-rows") val(tile_rows); else if (a == "--workspace-gib") val(workspace_gib);
         else if (a == "--frames-in-flight") val(kSlots);
         else if (a == "--spin" && i + 1 < argc) spin = (float)atof(argv[++i]);
-        else if (a == "--noise-table-tmax" && i + 1 < argc) table_tmax = (float)atof(argv[++i]);
+        else if (a == "--noise-table-gib" && i + 1 < argc) table_gib = atof(argv[++i]);
         else if (a == "--no-noise-table") use_table = 0;
         else if (a == "--force-collective") force_collective = 1;     // run the RCCL exchange even with one GPU (self-check)
         else if (a == "--out" && i + 1 < argc) out_path = argv[++i];
@@ -122,12 +129,14 @@ int main(int argc, char** argv) {
     if (gpus > n_dev) { fprintf(stderr, "rrt_headless: --gpus %d but %d device(s) visible\n", gpus, n_dev); return 2; }
     const bool collective = gpus > 1 || force_collective;
 
-    // the recording clock (main.cpp:511-516) says which times the noise tables must cover
-    if (use_table && table_tmax < 0.0f) {
-        float t_end = 0.0f, unused = 0.0f;
-        rrt_recording_clock(frames, fps, &t_end, &unused);
-        table_tmax = t_end + 1.0f;
-    }
+    // the recording clock (main.cpp:511-516) says which times the sequence reaches; the tables slide along it
+    float seq_end = 0.0f;
+    { float unused = 0.0f; rrt_recording_clock(frames, fps, &seq_end, &unused); seq_end += 1.0f; }
+    const size_t table_budget = table_gib > 0.0 ? (size_t)(table_gib * (double)(1ull << 30)) : 0;
+    if (table_budget == 0) use_table = 0;
+    int table_builds = 0, table_frames = 0, arith_frames = 0, coarsest = RRT_TABLE_FULL;
+    size_t table_peak = 0;
+    bool table_warned = false;
 
     const std::vector<uint8_t> sky = synthetic_sky(2048, 1024, sky_seed);
     rrt_effects fx; rrt_effects_default(&fx);
@@ -148,7 +157,6 @@ int main(int argc, char** argv) {
         D.id = d;
         HIPCHK(hipSetDevice(d));
         if ((rc = rrt_sky_create(sky.data(), 2048, 1024, &D.sky)) != RRT_OK) return fail("sky", rc);
-        if (use_table && (rc = rrt_noise_table_create(table_tmax, &D.noise_table)) != RRT_OK) return fail("noise table", rc);
         for (int s = 0; s < kSlots; ++s) {
             HIPCHK(hipStreamCreateWithFlags(&D.stream[s], hipStreamNonBlocking));
             HIPCHK(hipMalloc(&D.tiles[s], shard_stride));
@@ -202,6 +210,32 @@ int main(int argc, char** argv) {
         if (path >= 0 && (rc = rrt_path_camera_at(path, path_t, &cam)) != RRT_OK) return fail("camera", rc);
         // slot reuse: frame k-kSlots used the same buffers; its host copy must have been written out
         if (k > kSlots && deliver(slot)) return 1;
+        // 0. noise tables: when the clock has left the window, every device builds the next one (after its frames in
+        //    flight, which may still read the old table, have drained)
+        if (use_table && !(dev[0].noise_table && sim_t >= dev[0].table_t0 && sim_t <= dev[0].table_t1)) {
+            float t1 = sim_t; int cov = RRT_TABLE_FULL; size_t bytes = 0;
+            rrt_noise_table_fit_window(sim_t, seq_end > sim_t ? seq_end : sim_t, table_budget, &t1, &cov, &bytes);
+            for (int d = 0; d < gpus; ++d) {
+                Device& D = dev[d];
+                HIPCHK(hipSetDevice(d));
+                HIPCHK(hipDeviceSynchronize());
+                if (D.noise_table) { rrt_noise_table_destroy(D.noise_table); D.noise_table = 0; }
+                D.table_t0 = sim_t; D.table_t1 = sim_t - 1.0f;
+                if (bytes == 0) continue;
+                if ((rc = rrt_noise_table_create_window(sim_t, t1, cov, &D.noise_table)) != RRT_OK) {
+                    D.noise_table = 0;
+                    if (!table_warned) {
+                        fprintf(stderr, "rrt_headless: noise table [%g, %g] not built on device %d: %s (%s); hashing arithmetically\n",
+                                sim_t, t1, d, rrt_status_string(rc), rrt_last_hip_error());
+                        table_warned = true;
+                    }
+                    continue;
+                }
+                D.table_t1 = t1;
+            }
+            if (dev[0].noise_table) { ++table_builds; if (cov > coarsest) coarsest = cov; if (bytes > table_peak) table_peak = bytes; }
+        }
+        if (use_table && dev[0].noise_table && sim_t >= dev[0].table_t0 && sim_t <= dev[0].table_t1) ++table_frames; else ++arith_frames;
         // 1. every device renders its tiles
         for (int d = 0; d < gpus; ++d) {
             Device& D = dev[d];
@@ -242,9 +276,10 @@ int main(int argc, char** argv) {
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (f) fclose(f);
     printf("{\"frames\": %d, \"width\": %d, \"height\": %d, \"n_gpus\": %d, \"seconds\": %.4f, \"fps\": %.3f, \"Mrays_per_s\": %.3f, "
-           "\"path\": \"%s\", \"spin\": %g, \"arith_mode\": \"%s\", \"noise_table_tmax\": %g, \"collective\": \"%s\"}\n",
+           "\"path\": \"%s\", \"spin\": %g, \"arith_mode\": \"%s\", \"noise_tables\": {\"builds\": %d, \"table_frames\": %d, "
+           "\"arith_frames\": %d, \"coarsest_coverage\": %d, \"peak_bytes\": %zu, \"budget_bytes\": %zu}, \"collective\": \"%s\"}\n",
            frames, w, h, gpus, dt, frames / dt, (double)frames * w * h / dt / 1e6, path_name, spin, fast ? "fast" : "strict",
-           use_table ? table_tmax : 0.0f, collective ? "rccl grouped send/recv gather" : "none");
+           table_builds, table_frames, arith_frames, coarsest, table_peak, table_budget, collective ? "rccl grouped send/recv gather" : "none");
 
     for (int d = 0; d < gpus; ++d) {
         Device& D = dev[d];

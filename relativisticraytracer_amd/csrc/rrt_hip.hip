@@ -18,6 +18,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -48,10 +49,31 @@ int hip_fail(hipError_t e, const char* what) {
 /* ------------------------------------------------------------------ sky handles
  * A handle is an id into a process-wide registry, never a raw pointer: a stale or made-up handle is
  * reported as RRT_ERR_BAD_HANDLE instead of being dereferenced. */
+/* Every handle records the HIP device it was created on, and every entry point that would dereference its
+ * allocation from a kernel or a copy compares that with the calling thread's current device: a sky, workspace or
+ * noise table used under another hipSetDevice() is RRT_ERR_BAD_HANDLE, not a wild device pointer inside a kernel
+ * (the one-process N-GPU driver and the process-global launch defaults make that mistake easy).
+ * rrt_debug_fake_device() lets a CPU-only test drive those checks. */
+std::atomic<int> g_fake_device{-1};
+int current_device() {
+    const int fake = g_fake_device.load(std::memory_order_relaxed);
+    if (fake >= 0) return fake;
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return d;
+}
+/* -1 on either side (no HIP device could be asked) does not fail a launch by itself */
+bool on_current_device(int object_device) {
+    if (object_device < 0) return true;
+    const int d = current_device();
+    return d < 0 || d == object_device;
+}
+
 struct SkyObject {
     uint8_t* d_texels;
     int w, h;
     bool owned;
+    int device;
 };
 std::mutex g_sky_mu;
 std::unordered_map<unsigned long long, SkyObject> g_sky;
@@ -92,7 +114,7 @@ constexpr unsigned kBlockTrailer = kBlockRows * kRowData;         /* masks[kBloc
 constexpr unsigned kBlockBytes = kBlockTrailer + kBlockRows * 8 + 64;
 constexpr unsigned kNoBlock = 0xffffffffu;
 
-struct WorkspaceObject { uint8_t* d_base; size_t bytes; };
+struct WorkspaceObject { uint8_t* d_base; size_t bytes; int device; };
 std::mutex g_ws_mu;
 std::unordered_map<int, WorkspaceObject> g_ws;
 int g_ws_next = 1;
@@ -100,13 +122,15 @@ int g_ws_next = 1;
 /* ------------------------------------------------------------------ lattice-hash tables (rrt_noise_table)
  * Two dense boxes of the integer lattice, one for the accretion fbm and one for the dust-cloud noise calls
  * (layout and use: NoiseLut in rrt_device.h).  The boxes are computed on the host from the coordinate ranges
- * those calls can reach for 0 <= time <= t_max (lut_boxes below); a launch with a time outside that range
+ * those calls can reach for t0 <= time <= t1 (lut_boxes below); a launch with a time outside that window
  * simply runs the arithmetic kernels. */
 struct LutBox { int x0, y0, z0, nx, ny, nz; };
 struct NoiseTableObject {
     float4* d_cells;          /* accretion box, then dust box */
     size_t bytes;
-    float t_max;
+    float t0, t1;             /* launches with t0 <= time <= t1 read the table */
+    int coverage;             /* RRT_TABLE_FULL / _COARSE / _COARSEST */
+    unsigned acc_families, dust_families;
     LutBox acc, dust;
     int device;
 };
@@ -142,50 +166,94 @@ struct Reach {                 /* running union of the lattice points a noise3D 
     }
 };
 
-/* Coordinate ranges of the table-served noise calls for 0 <= time <= t_max, from the constants of
+/* Which noise3D call families a table of a given coverage serves (bit layout = the `from_table` words of
+ * accretion_density_at / dust_density_at in rrt_device.h).  The finest families dominate the volume of the dust box
+ * (it grows with the cube of the scale: 4.41^3 = 86 against 2.1^3 = 9 and 1), so a coarser coverage buys a table an
+ * order of magnitude smaller for sequences that run long. */
+void coverage_families(int coverage, unsigned& acc, unsigned& dust) {
+    acc = (1u << rrt::kLutAccOctaves) - 1u;
+    dust = 0xfu | (((1u << rrt::kLutRidgeOctaves) - 1u) << 4) | (rrt::kLutDetail ? 256u : 0u);
+    if (coverage >= RRT_TABLE_COARSE) dust &= ~((1u << 6) | 256u);              /* without ridge octave 2 (4.41 cells per unit) and the detail octave (4.0) */
+    if (coverage >= RRT_TABLE_COARSEST) { dust &= ~(1u << 5); acc &= 0x7u; }    /* without ridge octave 1 (2.1) and accretion octave 3 (3.9) */
+}
+
+/* Coordinate ranges of the table-served noise calls for t0 <= time <= t1, from the constants of
  * densities.h (every bound is taken generously: the functions only run for rc in [10, 25], the
  * accretion one for |y| < 4 and the dust one for |y| < 0.75 -- the zone tests of raymarcher.cu:57-58 --
- * |sin|, |cos| <= 1 + 1e-6, |atan2| <= pi + 1e-6, |noise3D| < 1 + 1e-6, hence |fbm(.,2)| < 0.76). */
-void lut_boxes(double t_max, LutBox& acc, LutBox& dust) {
+ * |sin|, |cos| <= 1 + 1e-6, |atan2| <= pi + 1e-6, |noise3D| < 1 + 1e-6, hence |fbm(.,2)| < 0.76).
+ * The dust box does NOT stay bounded for a window that slides: its z coordinate is 10 (azimuth - time * omega)
+ * with omega = (10/rc)^1.5 in [0.253, 1] (densities.h:88-93) -- differential rotation -- so the reachable z range
+ * is 10 [-(pi + max t omega), pi - min t omega]: its width grows like 0.75 t0 + (t1 - t0).  A window bounds it from
+ * both sides, a coarser coverage cuts the scale factor. */
+void lut_boxes(double t0, double t1, unsigned acc_fam, unsigned dust_fam, LutBox& acc, LutBox& dust) {
     const double pi = 3.14159265358979 + 1e-5;
+    const double slack = 1e-6 * (std::fabs(t0) + std::fabs(t1)) + 1e-3;      /* float rounding of time * rate at large times */
     {   /* getAccretionDensity, densities.h:44-54: (rc cos, 4y, rc sin)*0.45 + (0, 0.35 t, 0) */
         Reach r;
         Interval c[3] = {Interval{-25.0, 25.0}.scaled(0.45).widened(1e-3),
-                         Interval{-16.0, 16.0}.scaled(0.45).shifted(0.0, 0.35 * t_max).widened(1e-3),
+                         Interval{-16.0, 16.0}.scaled(0.45).shifted(0.35 * t0, 0.35 * t1).widened(slack),
                          Interval{-25.0, 25.0}.scaled(0.45).widened(1e-3)};
-        r.add_fbm(c, rrt::kLutAccOctaves);
+        int octaves = 0;
+        while (octaves < rrt::kLutAccOctaves && ((acc_fam >> octaves) & 1u)) ++octaves;
+        if (octaves == 0) octaves = 1;                         /* never an empty box */
+        r.add_fbm(c, octaves);
         acc = r.box();
     }
-    {   /* getDustCloudDensity, densities.h:93: coords = (0.8 rc, 15 y, 10 (phi - t*omega)), omega in (0, 1] */
+    {   /* getDustCloudDensity, densities.h:93: coords = (0.8 rc, 15 y, 10 (phi - t*omega)), omega in [0.25, 1] */
         Reach r;
+        const double w_lo = 0.25, w_hi = 1.0;
+        const double tw_max = t1 >= 0.0 ? t1 * w_hi : t1 * w_lo;          /* max of t * omega over the window */
+        const double tw_min = t0 >= 0.0 ? t0 * w_lo : t0 * w_hi;          /* min */
         const Interval sc[3] = {Interval{8.0, 20.0}.widened(1e-3), Interval{-11.25, 11.25}.widened(1e-3),
-                                Interval{-(pi + t_max) * 10.0, pi * 10.0}.widened(1e-2)};
+                                Interval{-(pi + tw_max) * 10.0, (pi - tw_min) * 10.0}.widened(1e-2 + 10.0 * slack)};
         const double off1[3][3] = {{0, 0, 0}, {1, 2, 3}, {4, 5, 6}}, off2[3][3] = {{0, 0, 0}, {2, 1, 0}, {0, 3, 1}};
+        const int w1_oct = (dust_fam & 2u) ? 2 : 1, w2_oct = (dust_fam & 8u) ? 2 : 1;
         for (int k = 0; k < 3; ++k) {                          /* :95-99 */
             Interval c[3];
             for (int ax = 0; ax < 3; ++ax) c[ax] = sc[ax].scaled(0.15).shifted(off1[k][ax], off1[k][ax]);
-            r.add_fbm(c, 2);
+            r.add_fbm(c, w1_oct);
         }
-        for (int k = 0; k < 3; ++k) {                          /* :101-106: (coords + 3 w1)*0.4 + offsets */
+        if (dust_fam & 4u) for (int k = 0; k < 3; ++k) {       /* :101-106: (coords + 3 w1)*0.4 + offsets */
             Interval c[3];
             for (int ax = 0; ax < 3; ++ax) c[ax] = sc[ax].widened(3.0 * 0.76).scaled(0.4).shifted(off2[k][ax], off2[k][ax]);
-            r.add_fbm(c, 2);
+            r.add_fbm(c, w2_oct);
         }
         double freq = 1.0;
         for (int k = 0; k < rrt::kLutRidgeOctaves; ++k) {      /* :111-120: (coords + 1.5 w2)*freq */
-            Interval c[3];
-            for (int ax = 0; ax < 3; ++ax) c[ax] = sc[ax].widened(1.5 * 0.76).scaled(freq);
-            r.add(c);
+            if ((dust_fam >> (4 + k)) & 1u) {
+                Interval c[3];
+                for (int ax = 0; ax < 3; ++ax) c[ax] = sc[ax].widened(1.5 * 0.76).scaled(freq);
+                r.add(c);
+            }
             freq *= 2.1;
         }
-        if (rrt::kLutDetail) {                                 /* :127: (coords + 1.5 w2)*4 + (0, 0.5 t, 0), first octave only */
+        if (rrt::kLutDetail && (dust_fam & 256u)) {            /* :127: (coords + 1.5 w2)*4 + (0, 0.5 t, 0), first octave only */
             Interval c[3];
             for (int ax = 0; ax < 3; ++ax) c[ax] = sc[ax].widened(1.5 * 0.76).scaled(4.0);
-            c[1] = c[1].shifted(0.0, 0.5 * t_max);
+            c[1] = c[1].shifted(0.5 * t0, 0.5 * t1).widened(slack);
             r.add_fbm(c, 1);
         }
         dust = r.box();
     }
+}
+
+/* noise3d_lut multiplies with 24-bit operands and addresses records with 32-bit byte offsets */
+bool lut_box_addressable(const LutBox& b) {
+    const size_t n = (size_t)b.nx * b.ny * b.nz;
+    return (size_t)b.nx * b.ny < ((size_t)1 << 23) && n < ((size_t)1 << 28) && b.nz < (1 << 23);
+}
+
+/* boxes + byte size of a table over [t0, t1] at `coverage`; RRT_ERR_INVALID_ARGUMENT for what create would refuse */
+int plan_table(float t0, float t1, int coverage, NoiseTableObject& nt) {
+    if (!(t0 <= t1) || !(t0 >= -1.0e4f) || !(t1 <= 1.0e4f)) return RRT_ERR_INVALID_ARGUMENT;
+    if (coverage < RRT_TABLE_FULL || coverage > RRT_TABLE_COARSEST) return RRT_ERR_INVALID_ARGUMENT;
+    memset(&nt, 0, sizeof(nt));
+    nt.t0 = t0; nt.t1 = t1; nt.coverage = coverage; nt.device = -1;
+    coverage_families(coverage, nt.acc_families, nt.dust_families);
+    lut_boxes((double)t0, (double)t1, nt.acc_families, nt.dust_families, nt.acc, nt.dust);
+    if (!lut_box_addressable(nt.acc) || !lut_box_addressable(nt.dust)) return RRT_ERR_INVALID_ARGUMENT;
+    nt.bytes = ((size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz + (size_t)nt.dust.nx * nt.dust.ny * nt.dust.nz) * sizeof(float4);
+    return RRT_OK;
 }
 
 __global__ __launch_bounds__(256) void build_noise_table(float4* cells, LutBox b) {
@@ -200,9 +268,10 @@ __global__ __launch_bounds__(256) void build_noise_table(float4* cells, LutBox b
     }
 }
 
-NoiseLut make_lut(const float4* cells, const LutBox& b) {
+NoiseLut make_lut(const float4* cells, const LutBox& b, unsigned families) {
     NoiseLut L;
     L.cells = cells;
+    L.families = families;
     L.nx = b.nx; L.nxy = b.nx * b.ny;
     L.origin = (b.z0 * b.ny + b.y0) * b.nx + b.x0;
     L.last = (unsigned)((size_t)b.nx * b.ny * b.nz - (size_t)L.nxy - 1);
@@ -547,8 +616,14 @@ __device__ __forceinline__ unsigned wave_index() {
 
 /* Single-kernel path: one ray per lane, media sampled in line (reference raymarch_kernel,
  * src/raymarcher.cu:15-174). */
+/* Register budgets: 64 VGPRs = 8 waves per SIMD for the bare march, 96 = 5 for the kernels that carry the media code
+ * (they need ~95; the next step down, 104-128 = 4 waves, costs the march inside them ~2 %: profiles/README.md round 3). */
+#ifndef RRT_MEDIA_WAVES
+#define RRT_MEDIA_WAVES 5
+#endif
 template <bool SPIN, int MEDIA, bool DEBUG, bool FAST>
-__global__ __launch_bounds__(kWGThreads) void raymarch_pixels(const FrameArgs a) {
+__global__ __launch_bounds__(kWGThreads, (MEDIA != 0 && !DEBUG ? RRT_MEDIA_WAVES : 1))      /* 2nd: minimum waves per SIMD */
+void raymarch_pixels(const FrameArgs a) {
     int x, y, out_row;
     if (!lane_pixel(a, x, y, out_row)) return;
     float uvx, uvy;
@@ -565,7 +640,7 @@ __global__ __launch_bounds__(kWGThreads) void raymarch_pixels(const FrameArgs a)
 /* amdgpu_num_sgpr(80): gfx950 admits 8 waves per SIMD only up to 80 SGPRs (7 for 82-96); this loop needs
  * the occupancy (measured: 4 waves/SIMD is 15 % slower than 8). */
 template <bool SPIN, bool FAST>
-__global__ __launch_bounds__(kWGThreads) __attribute__((amdgpu_num_sgpr(80))) void march_defer(const FrameArgs a) {
+__global__ __launch_bounds__(kWGThreads, 8) __attribute__((amdgpu_num_sgpr(80))) void march_defer(const FrameArgs a) {
     int x = 0, y = 0, out_row = 0;
     const bool valid = lane_pixel(a, x, y, out_row);
     if (!__any(valid)) return;
@@ -1094,7 +1169,7 @@ int fill_args(FrameArgs& a, int& media, bool& fast, int& workspace, int& policy,
     rrt_params prm;
     if (prm_in) prm = *prm_in; else rrt_params_default(&prm);
     SkyObject so;
-    if (!sky_lookup(sky, so)) return RRT_ERR_BAD_HANDLE;
+    if (!sky_lookup(sky, so) || !on_current_device(so.device)) return RRT_ERR_BAD_HANDLE;
     const SkyObject* s = &so;
     a.out = static_cast<uchar4*>(out);
     a.width = width; a.height = height; a.time = time; a.cam = *cam;
@@ -1118,11 +1193,12 @@ int fill_args(FrameArgs& a, int& media, bool& fast, int& workspace, int& policy,
             if (it == g_nt.end()) return RRT_ERR_BAD_HANDLE;
             nt = it->second;
         }
-        /* the boxes were sized for 0 <= time <= t_max; any other time runs the arithmetic kernels */
-        if (media && time >= 0.0f && time <= nt.t_max) {
+        if (!on_current_device(nt.device)) return RRT_ERR_BAD_HANDLE;
+        /* the boxes were sized for t0 <= time <= t1; any other time runs the arithmetic kernels (same bytes) */
+        if (media && time >= nt.t0 && time <= nt.t1) {
             media = 2;
-            a.lut_acc = make_lut(nt.d_cells, nt.acc);
-            a.lut_dust = make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust);
+            a.lut_acc = make_lut(nt.d_cells, nt.acc, nt.acc_families);
+            a.lut_dust = make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust, nt.dust_families);
         }
     }
     fast = prm.arith_mode == RRT_ARITH_FAST;
@@ -1200,6 +1276,7 @@ int launch(const FrameArgs& a, int media, bool debug, bool fast, int workspace, 
             if (it == g_ws.end()) return RRT_ERR_BAD_HANDLE;
             ws = it->second;
         }
+        if (!on_current_device(ws.device)) return RRT_ERR_BAD_HANDLE;
         const long long rays = (long long)a.width * a.rows.n_local_rows;
         const bool want = policy == RRT_PATH_THREE_PASS || (policy == RRT_PATH_AUTO && rays <= kThreePassMaxRays);
         if (media != 0 && !debug && want && a.max_steps <= kThreePassMaxSteps) {
@@ -1290,7 +1367,7 @@ int rrt_effects_default(rrt_effects* e) {    /* camera_settings.h:5-16 */
 
 int rrt_sky_create(const uint8_t* rgba8_host, int width, int height, rrt_sky_t* out) {
     if (!rgba8_host || !out || width <= 0 || height <= 0) return RRT_ERR_INVALID_ARGUMENT;
-    SkyObject s{nullptr, width, height, true};
+    SkyObject s{nullptr, width, height, true, current_device()};
     size_t bytes = (size_t)width * height * 4;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&s.d_texels), bytes);
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(sky)");
@@ -1302,7 +1379,12 @@ int rrt_sky_create(const uint8_t* rgba8_host, int width, int height, rrt_sky_t* 
 
 int rrt_sky_create_from_device(const void* d_rgba8, int width, int height, rrt_sky_t* out) {
     if (!d_rgba8 || !out || width <= 0 || height <= 0) return RRT_ERR_INVALID_ARGUMENT;
-    SkyObject s{const_cast<uint8_t*>(static_cast<const uint8_t*>(d_rgba8)), width, height, false};
+    /* the device that owns the caller's allocation, if the runtime can tell; else the current one */
+    int device = current_device();
+    hipPointerAttribute_t attr;
+    if (g_fake_device.load() < 0 && hipPointerGetAttributes(&attr, d_rgba8) == hipSuccess) device = attr.device;
+    else (void)hipGetLastError();
+    SkyObject s{const_cast<uint8_t*>(static_cast<const uint8_t*>(d_rgba8)), width, height, false, device};
     *out = sky_register(s);
     return RRT_OK;
 }
@@ -1325,7 +1407,7 @@ int rrt_sky_destroy(rrt_sky_t sky) {
 
 int rrt_workspace_create(size_t bytes, int* out) {
     if (!out || bytes < (size_t)1 << 20) return RRT_ERR_INVALID_ARGUMENT;
-    WorkspaceObject w{nullptr, bytes};
+    WorkspaceObject w{nullptr, bytes, current_device()};
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&w.d_base), bytes);
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(workspace)");
     std::lock_guard<std::mutex> lk(g_ws_mu);
@@ -1375,9 +1457,8 @@ int rrt_launch_raymarch_compat(void* d_out_rgba8, int width, int height, float t
     rrt_get_launch_defaults(&prm);
     const int rc = rrt_launch_raymarch(d_out_rgba8, width, height, time, &c, sky, &fx, &prm, nullptr);
     if (rc != RRT_OK) {
-        static bool said = false;
-        if (!said) {
-            said = true;
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true)) {
             fprintf(stderr, "launch_raymarch: %s%s%s (reported once)\n", rrt_status_string(rc),
                     rc == RRT_ERR_HIP ? " -- " : "", rc == RRT_ERR_HIP ? rrt_last_hip_error() : "");
         }
@@ -1407,6 +1488,7 @@ int rrt_workspace_stats(int id, unsigned* rows_used, unsigned* overflow_waves) {
         if (it == g_ws.end()) return RRT_ERR_BAD_HANDLE;
         w = it->second;
     }
+    if (!on_current_device(w.device)) return RRT_ERR_BAD_HANDLE;
     DeferCounters c;
     RRT_HIP(hipMemcpy(&c, w.d_base, sizeof(c), hipMemcpyDeviceToHost));
     if (rows_used) *rows_used = c.next_block * kBlockRows;
@@ -1423,28 +1505,19 @@ int rrt_workspace_read(int id, size_t offset, size_t bytes, void* host_dst) {
         w = it->second;
     }
     if (!host_dst || offset > w.bytes || bytes > w.bytes - offset) return RRT_ERR_INVALID_ARGUMENT;
+    if (!on_current_device(w.device)) return RRT_ERR_BAD_HANDLE;
     RRT_HIP(hipMemcpy(host_dst, w.d_base + offset, bytes, hipMemcpyDeviceToHost));
     return RRT_OK;
 }
 
-int rrt_noise_table_create(float t_max, int* out_id) {
-    if (!out_id || !(t_max >= 0.0f) || t_max > 1.0e4f) return RRT_ERR_INVALID_ARGUMENT;
+int rrt_noise_table_create_window(float t0, float t1, int coverage, int* out_id) {
+    if (!out_id) return RRT_ERR_INVALID_ARGUMENT;
     NoiseTableObject nt;
-    memset(&nt, 0, sizeof(nt));
-    nt.t_max = t_max;
-    lut_boxes((double)t_max, nt.acc, nt.dust);
-    const LutBox* boxes[2] = {&nt.acc, &nt.dust};
-    size_t cells = 0;
-    for (const LutBox* b : boxes) {
-        const size_t n = (size_t)b->nx * b->ny * b->nz;
-        /* noise3d_lut multiplies with 24-bit operands and addresses records with 32-bit byte offsets */
-        if ((size_t)b->nx * b->ny >= ((size_t)1 << 23) || n >= ((size_t)1 << 28) || b->nz >= (1 << 23)) return RRT_ERR_INVALID_ARGUMENT;
-        cells += n;
-    }
-    nt.bytes = cells * sizeof(float4);
+    const int rc = plan_table(t0, t1, coverage, nt);
+    if (rc != RRT_OK) return rc;
     RRT_HIP(hipGetDevice(&nt.device));
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&nt.d_cells), nt.bytes);
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc(noise table)");
+    if (e != hipSuccess) { (void)hipGetLastError(); snprintf(g_hip_err, sizeof(g_hip_err), "hipMalloc(noise table, %zu bytes): %s", nt.bytes, hipGetErrorString(e)); return e == hipErrorOutOfMemory ? RRT_ERR_OUT_OF_MEMORY : RRT_ERR_HIP; }
     hipLaunchKernelGGL(build_noise_table, dim3(4096), dim3(256), 0, nullptr, nt.d_cells, nt.acc);
     hipLaunchKernelGGL(build_noise_table, dim3(4096), dim3(256), 0, nullptr,
                        nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust);
@@ -1455,6 +1528,11 @@ int rrt_noise_table_create(float t_max, int* out_id) {
     *out_id = g_nt_next++;
     g_nt.emplace(*out_id, nt);
     return RRT_OK;
+}
+
+int rrt_noise_table_create(float t_max, int* out_id) {
+    if (!(t_max >= 0.0f)) return RRT_ERR_INVALID_ARGUMENT;
+    return rrt_noise_table_create_window(0.0f, t_max, RRT_TABLE_FULL, out_id);
 }
 
 int rrt_noise_table_destroy(int id) {
@@ -1476,21 +1554,64 @@ int rrt_noise_table_info(int id, float* t_max, size_t* bytes, int* boxes12) {
     auto it = g_nt.find(id);
     if (it == g_nt.end()) return RRT_ERR_BAD_HANDLE;
     const NoiseTableObject& nt = it->second;
-    if (t_max) *t_max = nt.t_max;
+    if (t_max) *t_max = nt.t1;
     if (bytes) *bytes = nt.bytes;
     if (boxes12) { memcpy(boxes12, &nt.acc, sizeof(LutBox)); memcpy(boxes12 + 6, &nt.dust, sizeof(LutBox)); }
     return RRT_OK;
 }
 
-/* boxes only (host arithmetic, no device): what rrt_noise_table_create(t_max) would allocate */
-int rrt_noise_table_plan(float t_max, size_t* bytes, int* boxes12) {
-    if (!(t_max >= 0.0f) || t_max > 1.0e4f) return RRT_ERR_INVALID_ARGUMENT;
-    LutBox a, d;
-    lut_boxes((double)t_max, a, d);
-    if (bytes) *bytes = ((size_t)a.nx * a.ny * a.nz + (size_t)d.nx * d.ny * d.nz) * sizeof(float4);
-    if (boxes12) { memcpy(boxes12, &a, sizeof(LutBox)); memcpy(boxes12 + 6, &d, sizeof(LutBox)); }
+int rrt_noise_table_window(int id, float* t0, float* t1, int* coverage, int* device) {
+    std::lock_guard<std::mutex> lk(g_nt_mu);
+    auto it = g_nt.find(id);
+    if (it == g_nt.end()) return RRT_ERR_BAD_HANDLE;
+    if (t0) *t0 = it->second.t0;
+    if (t1) *t1 = it->second.t1;
+    if (coverage) *coverage = it->second.coverage;
+    if (device) *device = it->second.device;
     return RRT_OK;
 }
+
+/* boxes only (host arithmetic, no device): what rrt_noise_table_create_window would allocate, with the same
+ * RRT_ERR_INVALID_ARGUMENT for a box it would refuse */
+int rrt_noise_table_plan_window(float t0, float t1, int coverage, size_t* bytes, int* boxes12) {
+    NoiseTableObject nt;
+    const int rc = plan_table(t0, t1, coverage, nt);
+    if (bytes) *bytes = rc == RRT_OK ? nt.bytes : 0;
+    if (rc != RRT_OK) return rc;
+    if (boxes12) { memcpy(boxes12, &nt.acc, sizeof(LutBox)); memcpy(boxes12 + 6, &nt.dust, sizeof(LutBox)); }
+    return RRT_OK;
+}
+
+int rrt_noise_table_plan(float t_max, size_t* bytes, int* boxes12) {
+    if (!(t_max >= 0.0f)) return RRT_ERR_INVALID_ARGUMENT;
+    return rrt_noise_table_plan_window(0.0f, t_max, RRT_TABLE_FULL, bytes, boxes12);
+}
+
+/* The window a frame driver should build next: the longest [t_from, t1], t1 <= t_until, at the richest coverage,
+ * whose table fits `budget_bytes` -- the window is halved (down to 0.5 s) before the coverage is lowered, because a
+ * rebuild costs milliseconds while a coarser table costs every frame.  RRT_OK with *bytes_out == 0 when nothing fits
+ * (the driver then renders without a table: same bytes, slower). */
+int rrt_noise_table_fit_window(float t_from, float t_until, size_t budget_bytes, float* t1_out, int* coverage_out, size_t* bytes_out) {
+    if (!t1_out || !coverage_out || !bytes_out || !(t_from <= t_until)) return RRT_ERR_INVALID_ARGUMENT;
+    *t1_out = t_from; *coverage_out = RRT_TABLE_FULL; *bytes_out = 0;
+    for (int cov = RRT_TABLE_FULL; cov <= RRT_TABLE_COARSEST; ++cov) {
+        float span = t_until - t_from;
+        for (;;) {
+            NoiseTableObject nt;
+            const float t1 = t_from + span;
+            if (plan_table(t_from, t1, cov, nt) == RRT_OK && nt.bytes <= budget_bytes) {
+                *t1_out = t1; *coverage_out = cov; *bytes_out = nt.bytes;
+                return RRT_OK;
+            }
+            if (span <= 0.5f) break;
+            span = span * 0.5f < 0.5f ? 0.5f : span * 0.5f;
+        }
+    }
+    return RRT_OK;
+}
+
+/* test hook: make every device check see `device` as the current one (< 0: ask HIP again) */
+int rrt_debug_fake_device(int device) { g_fake_device.store(device < 0 ? -1 : device); return RRT_OK; }
 
 int rrt_launch_raymarch_rows(void* d_out_rows, int width, int height, int y0, int y1, float time,
                              const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx,
@@ -1653,8 +1774,9 @@ int rrt_unit_noise3d_lut(int n, const float* p, int table, int which, float* out
         if (it == g_nt.end()) return RRT_ERR_BAD_HANDLE;
         nt = it->second;
     }
-    const NoiseLut L = which == 0 ? make_lut(nt.d_cells, nt.acc)
-                                  : make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust);
+    if (!on_current_device(nt.device)) return RRT_ERR_BAD_HANDLE;
+    const NoiseLut L = which == 0 ? make_lut(nt.d_cells, nt.acc, nt.acc_families)
+                                  : make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust, nt.dust_families);
     return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_noise3d_lut, g, b, 0, s, n, p, L, out, d_counts); });
 }
 int rrt_unit_media_lut(int n, const float* p, float time, int table, float* out_disk, float* out_dust, unsigned* d_counts, void* st) {
@@ -1666,9 +1788,10 @@ int rrt_unit_media_lut(int n, const float* p, float time, int table, float* out_
         if (it == g_nt.end()) return RRT_ERR_BAD_HANDLE;
         nt = it->second;
     }
-    if (!(time >= 0.0f && time <= nt.t_max)) return RRT_ERR_INVALID_ARGUMENT;
-    const NoiseLut la = make_lut(nt.d_cells, nt.acc);
-    const NoiseLut ld = make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust);
+    if (!on_current_device(nt.device)) return RRT_ERR_BAD_HANDLE;
+    if (!(time >= nt.t0 && time <= nt.t1)) return RRT_ERR_INVALID_ARGUMENT;
+    const NoiseLut la = make_lut(nt.d_cells, nt.acc, nt.acc_families);
+    const NoiseLut ld = make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust, nt.dust_families);
     return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_media_lut, g, b, 0, s, n, p, time, la, ld, out_disk, out_dust, d_counts); });
 }
 

@@ -146,6 +146,12 @@ RRT_FN float rrt_powf(float x, float y) {
 /* sin and cos of x together (|x| < ~8000 for full accuracy). */
 RRT_FN void rrt_sincosf(float x, float* sn, float* cs) {
     float ax = rrt_abs(x);
+    if (!(ax < 1.0e9f)) {                            /* NaN, infinity, or past the int conversion below (undefined in C, and
+                                                        different on CPUs and the GPU): NaN for NaN / infinity, (0, 1) otherwise */
+        const float nan_or_zero = x - x;
+        *sn = nan_or_zero; *cs = nan_or_zero + 1.0f;
+        return;
+    }
     int j = (int)(ax * 1.27323954473516f);           /* 4/pi */
     j = (j + 1) & ~1;
     float y = (float)j;

@@ -35,7 +35,10 @@ def main(argv=None):
     ap.add_argument("--workspace-gib", type=int, default=8,
                     help="per-rank pool for the three-pass path, used by launches of <= 1.5 M rays (0 = single kernel only)")
     ap.add_argument("--no-noise-table", action="store_true",
-                    help="hash every noise3D corner arithmetically (default: lattice-hash tables sized for the sequence's times)")
+                    help="hash every noise3D corner arithmetically (default: lattice-hash tables over a sliding window of the clock)")
+    ap.add_argument("--noise-table-gib", type=float, default=2.0,
+                    help="per-GPU byte budget of the noise tables: the window of sim time one table covers (and, for long "
+                         "sequences, its coverage) is chosen to fit; the table is rebuilt when the clock leaves the window")
     ap.add_argument("--out", default=None, help="x.rgba (raw, bottom-up) | dir/ (PPM per frame) | x.mp4 (needs ffmpeg)")
     args = ap.parse_args(argv)
 
@@ -67,19 +70,21 @@ def main(argv=None):
     # share of the pool
     n_slots = max(2, args.frames_in_flight) if world > 1 else 1
     pools = [rrt.Workspace((args.workspace_gib << 30) // n_slots) for _ in range(n_slots)] if args.workspace_gib > 0 else []
-    # lattice-hash tables for the volumetric noise, covering the times the recording clock will reach (main.cpp:511-516)
-    ntab = None
-    if not args.no_noise_table and not args.no_volumetrics:
-        t_end, _ = camera_paths.recording_clock(max(args.frames, 1), args.fps)
-        ntab = rrt.NoiseTable(float(t_end) + 1.0)
+    # lattice-hash tables for the volumetric noise over a sliding window of the recording clock (main.cpp:511-516 lets
+    # simTime grow without bound; the table's size grows with it): one table within the byte budget, rebuilt when the
+    # clock leaves its window -- never a silent fall-back: frames rendered without a table are counted in the summary
+    t_end, _ = camera_paths.recording_clock(max(args.frames, 1), args.fps)
+    nwin = rrt.NoiseWindows(float(t_end) + 1.0, int(args.noise_table_gib * (1 << 30)), sync=torch.cuda.synchronize,
+                            enabled=not args.no_noise_table and not args.no_volumetrics)
     prms = [rrt.RenderParams(spin=args.spin, volumetrics=0 if args.no_volumetrics else 1,
-                             noise_table=ntab.id if ntab else 0,
+                             noise_table=0,
                              arith_mode=1 if args.fast else 0, workspace=pools[j].id if pools else 0,
                              path_policy=int(os.environ.get("RRT_PATH_POLICY", "0"))) for j in range(n_slots)]
     path = camera_paths.CameraPath(args.path) if args.path >= 0 else None
-    state = {"t": 0.0, "cam": rrt.CameraState.default()}
+    state = {"t": 0.0, "cam": rrt.CameraState.default(), "table": 0}
 
     def render(buf, slot):
+        prms[slot].noise_table = state["table"]
         rrt.launch_raymarch_tiles(buf, w, h, args.tile_rows, rank, world, state["t"], state["cam"], tex, fx, prms[slot])
 
     def assemble(frame, buf, shard):
@@ -103,6 +108,7 @@ def main(argv=None):
     for k in range(1, args.frames + 1):
         sim_t, path_t = camera_paths.recording_clock(k, args.fps)
         state["t"] = sim_t
+        state["table"] = nwin.table_id(sim_t)
         if path is not None:
             state["cam"] = path.camera_at(path_t)
         frame = fs.step()
@@ -121,11 +127,11 @@ def main(argv=None):
         print(json.dumps({"frames": args.frames, "width": w, "height": h, "n_gpus": world, "seconds": round(dt, 4),
                           "fps": round(args.frames / dt, 3), "Mrays_per_s": round(args.frames * w * h / dt / 1e6, 3),
                           "path": path.name if path else None, "spin": args.spin,
-                          "arith_mode": "fast" if args.fast else "strict", "sink": args.out}), flush=True)
+                          "arith_mode": "fast" if args.fast else "strict", "sink": args.out,
+                          "noise_tables": nwin.summary()}), flush=True)
     if world > 1:
         dist.destroy_process_group()
-    if ntab:
-        ntab.destroy()
+    nwin.close()
     tex.destroy()
 
 

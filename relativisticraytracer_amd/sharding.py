@@ -73,9 +73,14 @@ class FrameSharder:
     """
 
     def __init__(self, width, height, tile_rows, rank, world, device, render, assemble, group=None,
-                 assemble_all=None, pipeline=False, collective_at_world1=False):
+                 assemble_all=None, pipeline=False, collective_at_world1=False, timing=False):
         import torch
         self.torch = torch
+        # timing=True (GPU buffers only): device events around the three phases of every step, on the stream the
+        # step runs on -- render | gather (queueing + waiting for the slowest rank + the transfer) | assemble --
+        # so that a multi-GPU run can explain its own efficiency; read them with phase_times()
+        self.timing = bool(timing) and torch.device(device).type == "cuda"
+        self.events = []
         self.width, self.height, self.tile_rows = width, height, tile_rows
         self.rank, self.world, self.group = rank, world, group
         self.pad_rows = max_shard_rows(height, tile_rows, world)
@@ -175,11 +180,29 @@ class FrameSharder:
         outs = list(self.gathered_alls[slot].split(self.n_bytes)) if self.rank == 0 else None
         return dist.gather(local, outs, dst=0, group=self.group, async_op=asyn), None
 
-    def _finish(self, work, staged, slot):
+    def _mark(self):
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()                      # on the current stream (the slot's stream inside _on())
+        return e
+
+    def phase_times(self, skip=0):
+        """Mean milliseconds per step of the recorded phases (after a device synchronise), ignoring the first `skip`
+        steps: {"render", "gather", "assemble", "steps"}.  With several frames in flight the phases of consecutive
+        frames overlap on the device, so these are each frame's own latencies, not shares of the step time."""
+        self.torch.cuda.synchronize()
+        ev = [e for e in self.events[skip:] if len(e) == 4]
+        if not ev:
+            return None
+        mean = lambda i: sum(e[i].elapsed_time(e[i + 1]) for e in ev) / len(ev)
+        return {"render": mean(0), "gather": mean(1), "assemble": mean(2), "steps": len(ev)}
+
+    def _finish(self, work, staged, slot, marks=None):
         """Wait for the slot's collective and assemble its frame (on the slot's stream)."""
         with self._on(slot):
             if work is not None:
                 work.wait()
+            if marks is not None:
+                marks.append(self._mark())          # the gathered shards are here
             if self.rank == 0:
                 ga, frame = self.gathered_alls[slot], self.frames[slot]
                 if staged is not None:
@@ -190,6 +213,8 @@ class FrameSharder:
                 else:
                     for s in range(self.world):
                         self.assemble(frame, ga[s * self.n_bytes:(s + 1) * self.n_bytes], s)
+            if marks is not None:
+                marks.append(self._mark())          # the frame is assembled
         if self.streams is not None:        # the caller reads the frame on its own (current) stream
             self.torch.cuda.current_stream().wait_stream(self.streams[slot])
         if self.rank == 0:
@@ -206,12 +231,18 @@ class FrameSharder:
             self.render(self.locals[slot], slot)
             self.assemble(self.frame, self.locals[slot], 0)
             return self.frame
+        marks = None
         with self._on(slot):
+            if self.timing:
+                marks = [self._mark()]
+                self.events.append(marks)
             self.render(self.locals[slot], slot)
+            if marks is not None:
+                marks.append(self._mark())          # this rank's shard is rendered
             work, staged = self._start_gather(slot)
         if not self.pipeline:
-            return self._finish(work, staged, slot)
-        self.pending.append((work, staged, slot))
+            return self._finish(work, staged, slot, marks)
+        self.pending.append((work, staged, slot, marks))
         if len(self.pending) < self.n_slots:
             return None
         return self._finish(*self.pending.pop(0))

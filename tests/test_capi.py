@@ -54,24 +54,21 @@ def test_launch_defaults_round_trip_without_a_device():
     assert rrt.get_launch_defaults().max_steps == 2000
 
 
-def test_noise_table_plan_covers_the_reachable_lattice():
-    """Host arithmetic only.  The boxes must contain the lattice cells of every table-served noise call; the
-    coordinates are re-derived here in float64 from densities.h for random in-zone points and times."""
+def _reachable_cells_inside(plan, t_lo, t_hi, coverage, seed):
+    """The boxes of `plan` must contain the lattice cells of every noise call the table serves at `coverage`; the
+    coordinates are re-derived here in float64 from densities.h for random in-zone points and times in [t_lo, t_hi]."""
     import numpy as np
-    import relativisticraytracer_amd as rrt
-    t_max = 32.0
-    plan = rrt.NoiseTable.plan(t_max)
-    assert plan["bytes"] < 1 << 30
     ax0, ay0, az0, anx, any_, anz = plan["accretion_box"]
     dx0, dy0, dz0, dnx, dny, dnz = plan["dust_box"]
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(seed)
     n = 200000
-    rc = rng.uniform(10.0, 25.0, n); ang = rng.uniform(-np.pi, np.pi, n); t = rng.uniform(0, t_max, n)
-    # accretion: (rc cos, 4y, rc sin)*0.45 + (0, 0.35 t, 0), |y| < 4, 4 octaves of p*2.05+10
+    rc = rng.uniform(10.0, 25.0, n); ang = rng.uniform(-np.pi, np.pi, n); t = rng.uniform(t_lo, t_hi, n)
+    t[:4] = (t_lo, t_hi, t_lo, t_hi); rc[:4] = (10.0, 10.0, 25.0, 25.0)
+    # accretion: (rc cos, 4y, rc sin)*0.45 + (0, 0.35 t, 0), |y| < 4, octaves of p*2.05+10 (4; 3 at the coarsest coverage)
     y = rng.uniform(-4, 4, n)
     rot = ang - t * 3.5 * (10.0 / rc) ** 1.5
     c = np.stack([rc * np.cos(rot) * 0.45, y * 4 * 0.45 + 0.35 * t, rc * np.sin(rot) * 0.45], 1)
-    for _ in range(4):
+    for _ in range(3 if coverage == 2 else 4):
         cell = np.floor(c)
         for k, (o, m) in enumerate(((ax0, anx), (ay0, any_), (az0, anz))):
             assert cell[:, k].min() >= o and cell[:, k].max() + 1 <= o + m - 1
@@ -86,13 +83,85 @@ def test_noise_table_plan_covers_the_reachable_lattice():
     for f in fams:
         pts += [f, f * 2.05 + 10]
     fc = sc + 1.5 * w
-    pts += [fc * 2.1 ** k for k in range(3)]
-    d = fc * 4 + np.stack([np.zeros(n), 0.5 * t, np.zeros(n)], 1)
-    pts += [d]
+    pts += [fc * 2.1 ** k for k in range({0: 3, 1: 2, 2: 1}[coverage])]     # ridge octaves served
+    if coverage == 0:
+        pts += [fc * 4 + np.stack([np.zeros(n), 0.5 * t, np.zeros(n)], 1)]   # detail octave
     for c in pts:
         cell = np.floor(c)
         for k, (o, m) in enumerate(((dx0, dnx), (dy0, dny), (dz0, dnz))):
             assert cell[:, k].min() >= o and cell[:, k].max() + 1 <= o + m - 1
+
+
+def test_noise_table_plan_covers_the_reachable_lattice():
+    """Host arithmetic only: [0, 32 s] at full coverage (the bench's table)."""
+    import relativisticraytracer_amd as rrt
+    plan = rrt.NoiseTable.plan(32.0)
+    assert plan["bytes"] < 1 << 30 and plan == rrt.NoiseTable.plan(32.0, 0.0, rrt.TABLE_FULL)
+    _reachable_cells_inside(plan, 0.0, 32.0, 0, 5)
+
+
+@pytest.mark.parametrize("t0,t1,coverage", [(495.0, 505.0, 1), (495.0, 505.0, 2), (120.0, 150.0, 0), (-20.0, -5.0, 0),
+                                            (-3.0, 4.0, 1), (2000.0, 2010.0, 2)])
+def test_noise_table_windows_cover_the_reachable_lattice(t0, t1, coverage):
+    """Sliding windows far along the reference's unbounded simTime (main.cpp:515), negative times, every coverage."""
+    import relativisticraytracer_amd as rrt
+    plan = rrt.NoiseTable.plan(t1, t0, coverage)
+    _reachable_cells_inside(plan, t0, t1, coverage, 11)
+
+
+def test_noise_table_plan_refuses_what_create_would_and_fit_stays_in_budget():
+    """plan() used to report 18 GB at 600 s although create() refuses that box; the frame drivers sized
+    their table to the sequence end with no budget.  Now plan == create's limits, and the drivers' policy
+    (rrt_noise_table_fit_window) returns the longest window / richest coverage within a byte budget."""
+    import relativisticraytracer_amd as rrt
+    with pytest.raises(rrt.RRTError):
+        rrt.NoiseTable.plan(600.0)                              # dust box >= 2^28 lattice points at full coverage
+    with pytest.raises(rrt.RRTError):
+        rrt.NoiseTable.plan(505.0, 495.0, rrt.TABLE_FULL)       # differential rotation: a window does not bound it
+    assert rrt.NoiseTable.plan(505.0, 495.0, rrt.TABLE_COARSE)["bytes"] < 2 << 30
+    with pytest.raises(rrt.RRTError):
+        rrt.NoiseTable.plan(1.0, 2.0)                           # t0 > t1
+    # coarser coverage, smaller table; longer window, larger table
+    sizes = [rrt.NoiseTable.plan(64.0, 32.0, c)["bytes"] for c in (0, 1, 2)]
+    assert sizes[0] > sizes[1] > sizes[2]
+    assert rrt.NoiseTable.plan(64.0, 0.0)["bytes"] > rrt.NoiseTable.plan(64.0, 32.0)["bytes"]
+    budget = 2 << 30
+    # a 12.5 s sequence (BASELINE config 5): one table, full coverage, whole sequence
+    t1, cov, nbytes = rrt.NoiseTable.fit(0.0, 13.5, budget)
+    assert (t1, cov) == (13.5, rrt.TABLE_FULL) and 0 < nbytes <= budget
+    # a ten-minute sequence: a shorter window first, then coarser tables, always inside the budget
+    t, n_windows, coarsest = 0.0, 0, 0
+    while t < 600.0 and n_windows < 200:
+        t1, cov, nbytes = rrt.NoiseTable.fit(t, 600.0, budget)
+        assert nbytes > 0 and nbytes <= budget and t1 > t
+        assert rrt.NoiseTable.plan(t1, t, cov)["bytes"] == nbytes
+        t, n_windows, coarsest = t1 + 1.0 / 24.0, n_windows + 1, max(coarsest, cov)
+    assert t >= 600.0 and 2 <= n_windows < 100 and coarsest >= rrt.TABLE_COARSE
+    # nothing fits: bytes == 0, and the caller renders without a table
+    assert rrt.NoiseTable.fit(5000.0, 5100.0, 64 << 20)[2] == 0
+
+
+def test_handles_are_tied_to_their_device_cpu_side():
+    """a sky created on one device and named in a launch under another current device is
+    RRT_ERR_BAD_HANDLE -- checked before anything touches HIP, so it can be driven on a CPU-only host through
+    the test hook rrt_debug_fake_device()."""
+    import relativisticraytracer_amd as rrt
+    from relativisticraytracer_amd import _lib
+    lib = _lib.load()
+    try:
+        assert lib.rrt_debug_fake_device(0) == 0
+        sky = C.c_ulonglong(0)
+        fake_texels = C.c_void_p(0x1000)                        # borrowed pointer: registered, never dereferenced here
+        assert lib.rrt_sky_create_from_device(fake_texels, 8, 4, C.byref(sky)) == 0
+        assert lib.rrt_debug_fake_device(3) == 0                # "hipSetDevice(3)"
+        cam, fx = rrt.CameraState.default(), rrt.CameraEffects()
+        out = C.c_void_p(0x2000)
+        rc = lib.rrt_launch_raymarch(out, 16, 8, 1.0, C.byref(cam), sky, C.byref(fx), None, None)
+        assert rc == 4 and lib.rrt_status_string(rc).decode().startswith("bad handle")
+        assert lib.rrt_launch_raymarch_tiles(out, 16, 8, 4, 0, 2, 1.0, C.byref(cam), sky, C.byref(fx), None, None) == 4
+        assert lib.rrt_sky_destroy(sky) == 0
+    finally:
+        lib.rrt_debug_fake_device(-1)
 
 
 def test_struct_layouts_match_the_reference_structs():

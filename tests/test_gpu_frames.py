@@ -1,13 +1,15 @@
 """Frame-level parity of the HIP path (through the C ABI) against the CPU oracle.
 
-Bars (north_star: "within 1e-4 relative per channel"):
-  * vs the oracle in PORTABLE math mode (same csrc/rrt_math.h on both sides):
-    RGBA8 bytes identical, float RGB / per-ray state bit-identical;
-  * vs the oracle in LIBM mode (glibc transcendentals, the independent check):
-    float RGB within 1e-4 relative (+1e-5 absolute floor for near-black
-    pixels), RGBA8 within 1 LSB, on >= 99.5 % of pixels -- the remainder are
-    rays whose hard density gates (raymarcher.cu:71,76,91; densities.h:85)
-    flip on a 1-ulp transcendental difference; their error is bounded too.
+Bars (north_star: "within 1e-4 relative per channel"), round 3: set to the MEASURED class, not a loose envelope --
+  * vs the oracle in PORTABLE math mode (same csrc/rrt_math.h on both sides): RGBA8 bytes identical, float RGB /
+    per-ray state bit-identical -- for the debug instantiation (which exposes the per-ray state) AND for the
+    production instantiation the bench times (bytes);
+  * vs the oracle in LIBM mode and vs the REFERENCE's own kernel body (glibc transcendentals, the independent
+    checks): step counts identical; RGBA8 within 1 LSB on <= 1e-4 of the bytes of a fixture (measured: 0 to 2 bytes
+    per frame) and <= 2e-5 at 4K / 1080p; float RGB within 1e-4 relative (+1e-5 absolute floor for near-black
+    pixels) on EVERY pixel whose hard-gate decisions (raymarcher.cu:71,76,91; densities.h:85; bloom threshold; the
+    sky filter's quantised weights) agree between the two math libraries -- tests/test_gate_accounting.py::account
+    recomputes the gate logs here -- and the flipped ones are counted (<= 2 per fixture frame).
 """
 import os
 
@@ -45,11 +47,31 @@ def _render(ctx, name, **kw):
     return g.render_gpu(w, h, spin, vol, cam, t, tex, fx=rrt.CameraEffects(**fxkw), **kw), cam
 
 
+def _gate_flips(po, sky, cam, ofx, prm_kw, t, w, h):
+    """Per pixel (h, w), in the frame's bottom-up storage order: do the hard-gate decisions of the two math
+    libraries differ for this ray?  (CPU: tests/test_gate_accounting.py::account)"""
+    from test_gate_accounting import account
+    a = cam.as_array()
+    acc = account(po, sky, po.camera(a[0], a[1], a[2], a[3]), ofx, prm_kw, t, w, h)
+    assert acc["forced_ok"].all()                                  # gates aligned: the libraries agree to 1e-4 everywhere
+    return acc["flipped"].reshape(h, w)[::-1]                      # account() lists rays top-down
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_golden_frames_byte_identical(ctx, frames_gold, name):
     r, cam = _render(ctx, name)
     assert np.array_equal(cam.as_array(), frames_gold[f"{name}_camera"])
     assert np.array_equal(r["rgba8"], frames_gold[f"{name}_portable_rgba8"])
+    # the PRODUCTION instantiation (debug=False: the kernel the bench times), and the same through the noise tables
+    g, rrt, tex = ctx
+    prod, _ = _render(ctx, name, debug=False)
+    assert np.array_equal(prod["rgba8"], frames_gold[f"{name}_portable_rgba8"])
+    nt = rrt.NoiseTable(16.0)
+    try:
+        prod, _ = _render(ctx, name, debug=False, noise_table=nt.id)
+        assert np.array_equal(prod["rgba8"], frames_gold[f"{name}_portable_rgba8"])
+    finally:
+        nt.destroy()
     assert np.array_equal(r["steps"], frames_gold[f"{name}_portable_steps"].astype(np.int32))
     assert np.array_equal(r["hit"], frames_gold[f"{name}_portable_hit"].astype(np.int32))
     if name != "G1":
@@ -60,20 +82,25 @@ def test_golden_frames_byte_identical(ctx, frames_gold, name):
 
 
 @pytest.mark.parametrize("name", list(CASES))
-def test_golden_frames_within_tolerance_of_libm_oracle(ctx, frames_gold, name):
-    r, _ = _render(ctx, name)
+def test_golden_frames_within_tolerance_of_libm_oracle(ctx, frames_gold, po, sky, name):
+    g, rrt, tex = ctx
+    r, cam = _render(ctx, name)
     # geodesic state involves only + - * / sqrt: identical in both oracle modes and on the GPU
     assert np.array_equal(r["steps"], frames_gold[f"{name}_libm_steps"].astype(np.int32))
     assert np.array_equal(r["hit"], frames_gold[f"{name}_libm_hit"].astype(np.int32))
     du8 = np.abs(r["rgba8"].astype(int) - frames_gold[f"{name}_libm_rgba8"].astype(int))
     assert du8.max() <= 1
-    assert (du8 > 0).mean() <= 0.005
+    assert (du8 > 0).sum() <= 1e-4 * du8.size, int((du8 > 0).sum())     # measured: 2 bytes of G1's 65 536, 0 elsewhere
     if name != "G1":
+        w, h, spin, vol, camspec, t, fxkw = CASES[name]
         ref = frames_gold[f"{name}_libm_ldr"][..., :3]
         got = r["ldr"][..., :3]
-        ok = np.abs(got - ref) <= 1e-4 * np.abs(ref) + 1e-5
-        assert ok.mean() >= 0.995
-        assert np.abs(got - ref).max() <= 2e-3
+        ok = (np.abs(got - ref) <= 1e-4 * np.abs(ref) + 1e-5).all(axis=2)
+        flips = _gate_flips(po, sky, cam, po.default_effects(use_ca=int(fxkw.get("useChromaticAberration", False))),
+                            {"spin": spin, "volumetrics": vol}, t, w, h)
+        assert (ok | flips).all(), "a pixel outside 1e-4 whose gate decisions agree in both math libraries"
+        assert (~ok).sum() <= 2, int((~ok).sum())                           # measured: 0 on every fixture
+        assert np.abs(got - ref)[ok].max() <= 5e-5                          # measured 1.2e-5
 
 
 def test_live_oracle_random_view(ctx, po, sky):
@@ -91,11 +118,15 @@ def test_live_oracle_random_view(ctx, po, sky):
     assert np.array_equal(r["rgba8"], o["rgba8"])
     assert same_bits(r["hdr"], o["hdr"]) and same_bits(r["ldr"], o["ldr"])
     assert np.array_equal(r["steps"], o["steps"])
+    prod = g.render_gpu(w, h, 0.9, 1, cam, 6.0, tex, fx=fx, debug=False)            # the production instantiation
+    assert np.array_equal(prod["rgba8"], o["rgba8"])
     ol = po.render(ocam, ofx, po.default_params(spin=0.9, math_mode=po.MATH_LIBM), 6.0, w, h, sky,
                    want=("rgba8", "ldr"))
-    ok = np.abs(r["ldr"][..., :3] - ol["ldr"][..., :3]) <= 1e-4 * np.abs(ol["ldr"][..., :3]) + 1e-5
-    assert ok.mean() >= 0.995
-    assert np.abs(r["rgba8"].astype(int) - ol["rgba8"].astype(int)).max() <= 1
+    ok = (np.abs(r["ldr"][..., :3] - ol["ldr"][..., :3]) <= 1e-4 * np.abs(ol["ldr"][..., :3]) + 1e-5).all(axis=2)
+    flips = _gate_flips(po, sky, cam, ofx, {"spin": 0.9}, 6.0, w, h)
+    assert (ok | flips).all() and (~ok).sum() <= 2                                   # measured: one flipped ray
+    d = np.abs(r["rgba8"].astype(int) - ol["rgba8"].astype(int))
+    assert d.max() <= 1 and (d > 0).sum() <= 2e-4 * d.size                           # measured: 1 byte of 20 736
 
 
 def test_effect_toggles_and_edge_sizes(ctx, po, sky):
@@ -292,7 +323,9 @@ def test_frames_against_the_reference_kernel(ctx, frames_ref, name):
     r = g.render_gpu(int(w), int(h), float(np.float32(spin)), int(vol), cam, float(np.float32(t)), tex, fx=fx)
     assert np.array_equal(r["steps"], frames_ref[f"{name}_steps"].astype(np.int32))
     d = np.abs(r["rgba8"].astype(int) - frames_ref[f"{name}_rgba8"].astype(int))
-    assert d.max() <= 1 and (d > 0).mean() <= 0.005
+    assert d.max() <= 1 and (d > 0).sum() <= 1e-4 * d.size, int((d > 0).sum())     # measured: 2 bytes on G1, 0 on the others
+    prod = g.render_gpu(int(w), int(h), float(np.float32(spin)), int(vol), cam, float(np.float32(t)), tex, fx=fx, debug=False)
+    assert np.array_equal(prod["rgba8"], r["rgba8"])                                # production instantiation: same bytes
 
 
 def test_random_scenes_against_the_reference_kernel_live(ctx, po, sky):
@@ -323,7 +356,8 @@ def test_random_scenes_against_the_reference_kernel_live(ctx, po, sky):
         d = np.abs(r["rgba8"].astype(int) - ref["rgba8"].astype(int))
         n_bytes += d.size; n_diff += int((d > 0).sum()); n_big += int((d > 1).sum())
         media += int(sc["vol"] and (r["rad"][:, 3] < 1.0).any())
-    assert n_diff <= 0.005 * n_bytes and n_big <= 0.0005 * n_bytes, (n_diff, n_big, n_bytes)
+    # measured on the default seed: 0 of 57 176 bytes differ; soaks with other seeds (RRT_SWEEP_SEED) stay inside this
+    assert n_diff <= 1e-4 * n_bytes + 2 and n_big <= 2e-5 * n_bytes + 1, (n_diff, n_big, n_bytes)
     assert media >= 5
 
 
@@ -349,7 +383,9 @@ def test_baseline_frames_against_the_reference_kernel_live(ctx, po, sky, w, h, s
     ys = np.arange(0, h, stride); xs = np.arange(0, w, stride); rows = h - 1 - ys
     assert np.array_equal(steps.cpu().numpy().reshape(h, w)[np.ix_(ys, xs)], ref["steps"].reshape(h, w)[np.ix_(ys, xs)])
     d = np.abs(out.cpu().numpy().reshape(h, w, 4)[np.ix_(rows, xs)].astype(int) - ref["rgba8"][np.ix_(rows, xs)].astype(int))
-    assert d.max() <= 1 and (d > 0).mean() <= 1e-3
+    # the whole 4K frame differs from the reference's in 165 of 33 177 600 bytes (5e-6: profiles/r02_dense_parity_vs_reference.txt);
+    # on these strided samples (39 900 / 28 928 bytes) the oracle finds none
+    assert d.max() <= 1 and (d > 0).sum() <= max(1, 2e-5 * d.size), int((d > 0).sum())
 
 
 def test_noise_table_path_is_byte_identical(ctx):
@@ -632,6 +668,153 @@ def test_baseline_configs_at_full_size_sampled_against_oracle(ctx, po, sky, name
     assert got[np.ix_(rows, xs)][..., :3].any()
 
 
+def test_config3_all_eight_shards_at_4k_assemble_to_the_single_launch(ctx, po, sky):
+    """BASELINE configs[3] as an 8-GPU workload, rehearsed on one GPU at FULL size: the 3840x2160 a = 0.99 frame
+    rendered as its eight interleaved 16-row-tile shards -- through the path a rank's launch actually takes (three-pass
+    pool for a share of 1.04 M rays, noise tables) -- into one gathered allocation, scattered by the single
+    rrt_assemble_all_tiles launch rank 0 runs after the gather: equal to the single launch of the same frame, byte
+    for byte, and to the oracle on every 101st pixel."""
+    import torch
+    g, rrt, tex = ctx
+    w, h, R, n = 3840, 2160, 16, 8
+    cam = rrt.CameraState.default(); fx = rrt.CameraEffects()
+    nt = rrt.NoiseTable(4.0); ws = rrt.Workspace(2 << 30)
+    try:
+        full = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+        rrt.launch_raymarch(full, w, h, 1.0, cam, tex, fx, rrt.RenderParams(spin=0.99, noise_table=nt.id))
+        pad = max(rrt.tile_shard_rows(h, R, s, n) for s in range(n)) * w * 4
+        assert sum(rrt.tile_shard_rows(h, R, s, n) for s in range(n)) == h
+        gathered = torch.zeros(n * pad, dtype=torch.uint8, device="cuda")
+        prm = rrt.RenderParams(spin=0.99, noise_table=nt.id, workspace=ws.id)          # RRT_PATH_AUTO: three-pass for <= 1.5 M rays
+        overflow = 0
+        for sh in range(n):
+            rrt.launch_raymarch_tiles(gathered[sh * pad:], w, h, R, sh, n, 1.0, cam, tex, fx, prm)
+            torch.cuda.synchronize()
+            st = ws.stats()
+            assert st["rows_used"] > 0, "the shard did not take the three-pass path"
+            overflow += st["overflow_waves"]
+        frame = torch.zeros_like(full)
+        rrt.assemble_all_tiles(frame, gathered, pad, w, h, R, n)
+        torch.cuda.synchronize()
+        assert torch.equal(frame, full), f"{int((frame != full).sum())} bytes differ"
+        # and without the pool (single kernel per shard), per-shard assembly
+        frame.zero_()
+        for sh in range(n):
+            buf = gathered[sh * pad:(sh + 1) * pad]; buf.zero_()
+            rrt.launch_raymarch_tiles(buf, w, h, R, sh, n, 1.0, cam, tex, fx, rrt.RenderParams(spin=0.99))
+            rrt.assemble_tiles(frame, buf, w, h, R, sh, n)
+        torch.cuda.synchronize()
+        assert torch.equal(frame, full)
+    finally:
+        nt.destroy(); ws.destroy()
+    stride = 101
+    a = cam.as_array()
+    o = po.render(po.camera(a[0], a[1], a[2], a[3]), po.default_effects(), po.default_params(spin=0.99, math_mode=po.MATH_PORTABLE),
+                  1.0, w, h, sky, stride=(stride, stride))["rgba8"]
+    ys = np.arange(0, h, stride); xs = np.arange(0, w, stride); rows = h - 1 - ys
+    assert np.array_equal(frame.cpu().numpy().reshape(h, w, 4)[np.ix_(rows, xs)], o[np.ix_(rows, xs)])
+
+
+def test_noise_table_windows_far_along_the_clock(ctx):
+    """the reference's simTime runs without bound (main.cpp:515).  A frame at t = 500 s through a
+    [495, 505] window (coarse coverage: at full coverage the differential rotation of the dust coordinates makes
+    that box unaddressable, see rrt.h) equals the arithmetic frame, no table read is ever clamped, a time outside
+    the window falls back to the arithmetic kernels, every coverage gives the same bytes, and the drivers' policy
+    object walks a clock across several windows inside its budget."""
+    import torch
+    g, rrt, tex = ctx
+    views = [(960, 540, (4.2, 0.6, 4.2), -90.0, -5.7), (640, 360, (35.0, 0.8, 10.0), -106.0, -1.2), (480, 270, (0.0, 10.0, -60.0), 0.0, -10.0)]
+    fx = rrt.CameraEffects()
+    with pytest.raises(rrt.RRTError):
+        rrt.NoiseTable.window(495.0, 505.0, rrt.TABLE_FULL)
+    for t0, t1, cov, t in ((495.0, 505.0, rrt.TABLE_COARSE, 500.0), (495.0, 505.0, rrt.TABLE_COARSEST, 503.25),
+                           (10.0, 20.0, rrt.TABLE_FULL, 14.0), (10.0, 20.0, rrt.TABLE_COARSE, 14.0), (-8.0, -2.0, rrt.TABLE_FULL, -5.5)):
+        nt = rrt.NoiseTable.window(t0, t1, cov)
+        try:
+            info = nt.info()
+            assert (info["t0"], info["t1"], info["coverage"]) == (t0, t1, cov) and info["bytes"] == rrt.NoiseTable.plan(t1, t0, cov)["bytes"]
+            for (w, h, pos, yaw, pitch) in views:
+                cam = rrt.CameraState.from_angles(pos, yaw, pitch)
+                ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda"); out = torch.zeros_like(ref)
+                rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9))
+                rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id))
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref), (t0, t1, cov, t, pos)
+                oob = torch.zeros(1, dtype=torch.int32, device="cuda")
+                rrt.launch_raymarch_debug(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id), lut_oob=oob)
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref) and int(oob.item()) == 0, (t0, t1, cov, t, pos)
+            # just outside the window: the arithmetic kernels, same bytes
+            w, h, pos, yaw, pitch = views[1]
+            cam = rrt.CameraState.from_angles(pos, yaw, pitch)
+            for tt in (t0 - 0.5, t1 + 0.5):
+                ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda"); out = torch.zeros_like(ref)
+                rrt.launch_raymarch(ref, w, h, tt, cam, tex, fx, rrt.RenderParams(spin=0.9))
+                rrt.launch_raymarch(out, w, h, tt, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id))
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref), tt
+        finally:
+            nt.destroy()
+    # the policy object of the frame drivers: 40 s of clock with a 0.3 GiB budget needs several windows
+    nw = rrt.NoiseWindows(40.0, int(0.3 * (1 << 30)), sync=torch.cuda.synchronize)
+    w, h, pos, yaw, pitch = views[1]
+    cam = rrt.CameraState.from_angles(pos, yaw, pitch)
+    ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda"); out = torch.zeros_like(ref)
+    try:
+        for k in range(0, 40 * 24, 37):
+            t = k / 24.0
+            rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9))
+            rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nw.table_id(t)))
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), t
+        sm = nw.summary()
+        assert sm["builds"] >= 2 and sm["arith_frames"] == 0 and sm["peak_bytes"] <= sm["budget_bytes"], sm
+    finally:
+        nw.close()
+
+
+def test_handles_are_tied_to_their_device(ctx):
+    """VERDICT r02 item 7 / ADVICE: a sky, workspace or noise table used while another device is current is
+    RRT_ERR_BAD_HANDLE, not a wild device pointer in a kernel.  One GPU here, so "another device" is the test hook
+    rrt_debug_fake_device(); on the real device everything launches."""
+    import ctypes as C
+    import torch
+    from relativisticraytracer_amd import _lib
+    g, rrt, tex = ctx
+    lib = _lib.load()
+    w, h = 64, 36
+    cam = rrt.CameraState.default(); fx = rrt.CameraEffects()
+    out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+    nt = rrt.NoiseTable(2.0); ws = rrt.Workspace(64 << 20)
+    real = torch.cuda.current_device()
+    try:
+        assert nt.info()["device"] == real
+        rrt.launch_raymarch(out, w, h, 1.0, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=ws.id, path_policy=2))
+        torch.cuda.synchronize()
+        ref = out.clone()
+        lib.rrt_debug_fake_device(real + 1)
+        for prm in (rrt.RenderParams(spin=0.9), rrt.RenderParams(spin=0.9, noise_table=nt.id)):
+            with pytest.raises(rrt.RRTError) as e:
+                rrt.launch_raymarch(out, w, h, 1.0, cam, tex, fx, prm)
+            assert e.value.status == 4
+        # a sky of the "other" device with a table / pool of this one: each is checked on its own
+        sky2 = C.c_ulonglong(0)
+        assert lib.rrt_sky_create_from_device(C.c_void_p(out.data_ptr()), 8, 4, C.byref(sky2)) == 0      # registered under the fake device
+        a = cam
+        for prm in (rrt.RenderParams(spin=0.9, noise_table=nt.id), rrt.RenderParams(spin=0.9, workspace=ws.id, path_policy=2)):
+            assert lib.rrt_launch_raymarch(C.c_void_p(out.data_ptr()), w, h, 1.0, C.byref(a), sky2, C.byref(fx), C.byref(prm), None) == 4
+        assert lib.rrt_workspace_stats(ws.id, None, None) == 4
+        lib.rrt_sky_destroy(sky2)
+        lib.rrt_debug_fake_device(-1)
+        out.zero_()
+        rrt.launch_raymarch(out, w, h, 1.0, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=ws.id, path_policy=2))
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    finally:
+        lib.rrt_debug_fake_device(-1)
+        nt.destroy(); ws.destroy()
+
+
 def test_full_size_properties_4k(ctx):
     """BASELINE config at full size: properties that need no oracle.
     Two launches give identical bytes (no races); every alpha is 255; the image is left-right
@@ -747,6 +930,9 @@ def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
             r = g.render_gpu(w, h, spin, 1, cam, t, tex, fx=fx, noise_table=nt.id)       # same through the noise tables
             assert np.array_equal(r["rgba8"], o["rgba8"]) and same_bits(r["ldr"], o["ldr"]), tag
             assert int(r["lut_oob"][0]) == 0, tag
+            for table in (0, nt.id):                                                     # the production instantiations (debug off)
+                r = g.render_gpu(w, h, spin, 1, cam, t, tex, fx=fx, debug=False, noise_table=table)
+                assert np.array_equal(r["rgba8"], o["rgba8"]), (tag, "production kernel", table)
             want = torch.from_numpy(o["rgba8"].reshape(-1)).cuda()
             for pool in (ample, starved):
                 out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
