@@ -273,6 +273,9 @@ int rrt_selfcheck_div(unsigned long long n_cases, uint32_t seed, unsigned long l
 /* the march's transcendental-free square root (csrc/rrt_device.h: sqrt_seeded) over a range of float bit patterns
  * and a ladder of seed errors; d_counters[3] receives the number of accepted (checked) cases */
 int rrt_selfcheck_sqrt_seeded(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* stream);
+/* the media code's three-instruction division by a compile-time constant (csrc/rrt_device.h: rrt_div_const): every
+ * dividend with bits in [lo_bits, hi_bits), both signs, for each constant the media code divides by */
+int rrt_selfcheck_div_const(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* stream);
 /* the media code's scaling-free division (csrc/rrt_device.h: rrt_div_tame) on random tame operand pairs */
 int rrt_selfcheck_div_tame(unsigned long long n_cases, uint32_t seed, unsigned long long* d_counters, void* stream);
 

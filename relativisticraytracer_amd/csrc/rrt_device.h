@@ -46,6 +46,28 @@ __device__ __forceinline__ float rrt_div_tame(float a, float b) { return rrt_div
 __host__ __device__ static inline float rrt_div_tame(float a, float b) { return a / b; }   /* host pass: never executed */
 #endif
 
+/*
+ * a / B for a compile-time constant B (round 3): y = RN(1/B) is folded at compile time and is the CORRECTLY ROUNDED
+ * reciprocal, which is exactly Markstein's hypothesis: q = RN(a*y) is a faithful quotient, r = a - B*q is exact in one
+ * fma, and RN(q + r*y) is the correctly rounded a / B -- three instructions instead of the ten of rrt_div_tame (whose
+ * v_rcp seed alone costs as much as the Newton step behind it).  Valid where nothing under- or overflows: callers pass
+ * bounded dividends (each use site says so); rrt_selfcheck_div_const checks EVERY dividend of magnitude 2^[-40, 40) (and
+ * +0) against IEEE `/` for every constant the media code divides by.  (A -0 dividend would return +0 for B > 0; the use
+ * sites cannot produce one: their dividends are differences with non-zero literals, or radii / temperatures >= 1.)
+ */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RRT_NO_LEAN) && !defined(RRT_NO_CONST_DIV)
+/* B must be a literal (or constexpr) at the call site: `1.0f / B` is then folded by the compiler, correctly rounded.
+ * (With a run-time B this is still a / B exactly -- the reciprocal would be IEEE-divided at run time -- only slow.) */
+__device__ __forceinline__ float rrt_div_const(float a, const float B) {
+    const float y = 1.0f / B;
+    const float q = a * y;
+    const float r = __builtin_fmaf(-B, q, a);
+    return __builtin_fmaf(r, y, q);
+}
+#else
+__host__ __device__ static inline float rrt_div_const(float a, const float B) { return a / B; }
+#endif
+
 #include "rrt_math.h"
 
 #define RRT_DEV __device__ __forceinline__
@@ -254,7 +276,7 @@ RRT_DEV float sqrt_tame(float x) { float r, y; sqrt_rsq(x, r, y); return r; }
  * the dividend a bounded difference, so the division is tame (a zero dividend gives the IEEE zero) */
 template <bool LEAN>
 RRT_DEV float smoothstep_t(float e0, float e1, float x) {
-    const float q = LEAN ? rrt_div_tame(x - e0, e1 - e0) : (x - e0) / (e1 - e0);
+    const float q = LEAN ? rrt_div_const(x - e0, e1 - e0) : (x - e0) / (e1 - e0);   /* literal edges: a constant divisor */
     const float t = fmin2(fmax2(q, 0.0f), 1.0f);
     return t * t * (3.0f - 2.0f * t);
 }
@@ -523,18 +545,34 @@ RRT_DEV v3 geodesic_acc_ng(v3 p, v3 v, float drag_c, float r2, float r, float y,
 /* One RK4 step (integrators.h:23-59) from the loop-top radius (r2, r, y, h) of the pre-step position; (y_next,
  * h_next) = the reciprocal radius of the last stage position, the seed of the next step's loop-top root.
  * The loop-top radius has passed the caller's horizon test (r >= 2.02), so stage 1 needs no `r < 1` case.  VAC: h = STEP_SIZE_M exactly (no zone applies), constants folded. */
+#ifndef RRT_EXTRAP_SEEDS
+#define RRT_EXTRAP_SEEDS 1
+#endif
+/* VAC only (RRT_EXTRAP_SEEDS): the two-iteration roots of stages 2 and 4 become one-iteration roots with a seed
+ * extrapolated LINEARLY from the two reciprocal radii half a step apart that the march already holds -- stage 4 from
+ * (loop top, stage 3), stage 2 from (the previous vacuum step's stage 3 ~ its stage 2 position, this loop top): the
+ * error is y'' (h/2)^2 <= 2 (h / 2r)^2 = 5e-5 relative at r = 30, inside the one-iteration tolerance kSeedTol, and the
+ * acceptance test catches everything else (first vacuum step after a step of another size: hc_prev belongs to
+ * another spacing, the seed is rejected, the v_rsq fall-back runs once).  -2 instructions per vacuum step. */
 template <bool SPIN, bool VAC>
 RRT_DEV void integrate_rk4_lean(v3& p, v3& v, float h_in, float hh_in, float h6_in, float drag_c,
-                                float r2, float r, float y, float hy, float& y_next, float& h_next) {
+                                float r2, float r, float y, float hy, float& y_next, float& h_next, float& hc_prev) {
     const float h = VAC ? kStepSize : h_in;
     const float hh = VAC ? 0.5f * kStepSize : hh_in;
     const float h6 = VAC ? kStepSize / 6.0f : h6_in;
+    constexpr bool EXTRAP = VAC && RRT_EXTRAP_SEEDS;
     v3 p0 = p, v0 = v;
     v3 kv1 = geodesic_acc_ng<SPIN>(p0, v0, drag_c, r2, r, y, 0ull);
     v3 v2 = add(v0, mul(kv1, hh));
     v3 p2 = add(p0, mul(v0, hh));
     float r2b = dot(p2, p2), rb, yb, hb;
-    const unsigned long long sb = stage_radius_yh<2>(r2b, y, hy, rb, yb, hb);
+    unsigned long long sb;
+    if (EXTRAP) {
+        const float h0 = __builtin_fmaf(2.0f, hy, -hc_prev);
+        sb = stage_radius_yh<1>(r2b, h0 + h0, h0, rb, yb, hb);
+    } else {
+        sb = stage_radius_yh<2>(r2b, y, hy, rb, yb, hb);
+    }
     v3 kv2 = geodesic_acc_ng<SPIN>(p2, v2, drag_c, r2b, rb, yb, sb);
     v3 v3_ = add(v0, mul(kv2, hh));
     v3 p3 = add(p0, mul(v2, hh));
@@ -544,7 +582,14 @@ RRT_DEV void integrate_rk4_lean(v3& p, v3& v, float h_in, float hh_in, float h6_
     v3 v4 = add(v0, mul(kv3, h));
     v3 p4 = add(p0, mul(v3_, h));
     float r2d = dot(p4, p4), rd, yd, hd;
-    const unsigned long long sd = stage_radius_yh<2>(r2d, yc, hc, rd, yd, hd);
+    unsigned long long sd;
+    if (EXTRAP) {
+        const float h0 = __builtin_fmaf(2.0f, hc, -hy);
+        sd = stage_radius_yh<1>(r2d, h0 + h0, h0, rd, yd, hd);
+    } else {
+        sd = stage_radius_yh<2>(r2d, yc, hc, rd, yd, hd);
+    }
+    hc_prev = VAC ? hc : 0.0f;            /* a generic step has another spacing: no extrapolation across it */
     v3 kv4 = geodesic_acc_ng<SPIN>(p4, v4, drag_c, r2d, rd, yd, sd);
     v3 kv_sum, kp_sum;
     kv_sum.x = kv1.x + __builtin_fmaf(2.0f, kv2.x, __builtin_fmaf(2.0f, kv3.x, kv4.x));
@@ -649,7 +694,7 @@ RRT_DEV float redshift_factor(v3 p, v3 ray_vel, float spin) { return redshift_fa
 template <bool LEAN>
 RRT_DEV float disk_temperature_t(float r) {
     if (r < kIsco) return 0.0f;
-    const float x = (LEAN && r < 64.0f) ? rrt_div_tame(r, kIsco) : r / kIsco;
+    const float x = (LEAN && r < 64.0f) ? rrt_div_const(r, kIsco) : r / kIsco;
     return kDiskTempRef * rrt_powf(x, -0.75f);
 }
 RRT_DEV float disk_temperature(float r) { return disk_temperature_t<false>(r); }
@@ -731,6 +776,12 @@ RRT_DEV bool disk_point(v3 p, DiskPoint& d) {           /* false: outside the ra
     if (LEAN && !(rc2 >= 1.0f)) return false;          /* rc < 1 < ISCO; keeps sqrt_tame in range */
     d.rc = Ar<LEAN>::sqrt(rc2);
     if (d.rc < kIsco || d.rc > kDiskOut) return false;
+    /* Exact early-out (round 3, render kernels): far from the mid-plane both densities are 0 before anything else is
+     * computed.  The accretion slab exponent is -y^2 rc / (12.8 + 1e-7 rc) up to 1e-6 relative (thick^2 = 0.64 * 10/rc),
+     * so y^2 rc > 135 puts it below -10.54 < -10.5, where accretion_density_at returns 0 (its pre-test); the dust slab
+     * there is e^(-y^2 / 0.125) <= e^-43, far under the `base < 0.001f` return of densities.h:85.  A quarter of the
+     * accretion calls of the outer disk end here, 12 instructions in, instead of behind two divides and two roots. */
+    if (LEAN && (p.y * p.y) * d.rc > 135.0f) return false;
     d.q = Ar<LEAN>::div(kIsco, d.rc);                   /* in [0.4, 1] */
     d.sq = Ar<LEAN>::sqrt(d.q);                         /* == powf(q, 0.5f); q * sq == powf(q, 1.5f) (rrt_math.h) */
     d.azimuth = 0.0f; d.has_azimuth = false;
@@ -750,14 +801,20 @@ RRT_DEV float accretion_density_at(v3 p, float time, DiskPoint& dp, const NoiseL
     constexpr bool LEAN = EARLY_OUT;
     const float rc = dp.rc, q = dp.q;
 
+    const float thick = kDiskH * dp.sq;                /* DISK_H_M * powf(q, 0.5f) */
+    const float slab_arg = Ar<LEAN>::div(-(p.y * p.y), 2.0f * thick * thick + 1e-7f);
+    /* Exact pre-test of the early-out below (round 3), before expf / powf / the rim are paid for: slab <= e^-10.5
+     * (1 + 3e-7) < 2.7537e-5, fall = q^0.4 <= 1 + 3e-7 (q <= 1) and rim <= 1, so envelope * 30.02f < 8.3e-4 <= 0.001f and
+     * the test below returns 0 as well.  Beyond 4.58 scale heights -- a quarter of the disk zone's |y| < 4 at the outer
+     * radii -- nothing else of this function is evaluated.  (NaN compares false and takes the long way.) */
+    if (EARLY_OUT && slab_arg < -10.5f) return 0.0f;
     float rim = 1.0f;                                   /* taper of the outer 15 % (:25-30) */
     const float rim_from = kDiskOut * 0.85f;
     if (rc > rim_from) {
-        rim = 1.0f - Ar<LEAN>::div(rc - rim_from, kDiskOut - rim_from);
+        rim = 1.0f - (LEAN ? rrt_div_const(rc - rim_from, kDiskOut - rim_from) : (rc - rim_from) / (kDiskOut - rim_from));
         rim *= rim;
     }
-    const float thick = kDiskH * dp.sq;                /* DISK_H_M * powf(q, 0.5f) */
-    const float slab = rrt_expf(Ar<LEAN>::div(-(p.y * p.y), 2.0f * thick * thick + 1e-7f));
+    const float slab = rrt_expf(slab_arg);
     const float fall = rrt_powf(q, 0.4f);
     const float envelope = slab * fall * rim;
 
@@ -885,6 +942,11 @@ RRT_DEV float dust_density_at(v3 p, float time, DiskPoint& dp, const NoiseLut& L
     const unsigned ridge_bits = (from_table >> 4) & ((1u << kLutRidgeOctaves) - 1u);
 #pragma unroll 1
     for (int k = 0; k < 5; ++k) {
+        /* Exact early-out (round 3, render kernels only): every ridge term is <= amp (1 - |2 noise - 1| <= 1), so the
+         * finished sum is <= n + 2 amp (the remaining amplitudes amp, amp/2 ... add up to < 2 amp; the float sum of at
+         * most five such terms stays within 1e-6 of that).  If even that gives n * 0.55f <= 0.4f, the smoothstep below
+         * is 0, strands is 0 and so is the density: the remaining octaves and the detail fbm cannot change it. */
+        if (LEAN && k > 0 && n + 2.0f * amp <= 0.7272f) return 0.0f;
         if (LUT && RRT_LUT_PAIRS && ((ridge_bits >> k) & 3u) == 3u) {
             float n0, n1;
             noise3d_lut_pair(L, mul(fc, freq), mul(fc, freq * 2.1f), oob, n0, n1);
@@ -903,6 +965,10 @@ RRT_DEV float dust_density_at(v3 p, float time, DiskPoint& dp, const NoiseLut& L
     }
     float strands = smoothstep_t<LEAN>(0.4f, 0.8f, n * 0.55f);
     strands = rrt_powf(strands, 4.0f);
+    /* Exact early-out (round 3, render kernels only): detail = fbm(.,2) < 0.75, so the factor below is < 0.9000004 and
+     * the result < envelope * strands * 10.800005 (1 + 2e-7); at or under 9.25e-5 that is < 0.000999 <= 0.001f: the
+     * caller's `d_cloud > 0.001f` gates (raymarcher.cu:71,91) discard it whatever the detail noise is. */
+    if (LEAN && envelope * strands <= 9.25e-5f) return 0.0f;
     const v3 dc = mul(fc, 4.0f);
     const float detail = fbm2_sel<LUT>(mk(dc.x + 0.0f, dc.y + time * 0.5f, dc.z + 0.0f), L, from_table & 256u, false, oob);
     strands *= (0.6f + 0.4f * detail);
@@ -946,7 +1012,7 @@ RRT_DEV bool sample_emission(float d_disk, float d_cloud, v3 rel_p, float r, v3 
     if (disk_on) {                                               /* thermal disk, raymarcher.cu:76-88 */
         const float temp = disk_temperature_t<true>(r);
         const bool tame = temp >= 1.0f;                          /* temp in [6.6e6, 1.5e7] for r in [10, 30) */
-        const float rel_temp = tame ? rrt_div_tame(temp, kDiskTempRef) : temp / kDiskTempRef;
+        const float rel_temp = tame ? rrt_div_const(temp, kDiskTempRef) : temp / kDiskTempRef;
         const float root_temp = tame ? sqrt_tame(rel_temp) : rrt_powf(rel_temp, 0.5f);
         const float power = rrt_powf(shift_g, 4.0f) * root_temp * d_disk * kDiskLum;
         const float hue = shift_g * rrt_powf(rel_temp, 0.4f) * 2.5f;
@@ -959,7 +1025,11 @@ RRT_DEV bool sample_emission(float d_disk, float d_cloud, v3 rel_p, float r, v3 
         const float rr = fmax2(r, kIsco);
         const float lit = 0.5f + 3.0f * rrt_powf(rr < 64.0f ? rrt_div_tame(kIsco, rr) : kIsco / rr, 1.2f);
         const float glow = d_cloud * kCloudLum * lit;
-        const float grade = smoothstep(0.7f, 1.3f, shift_g);
+        /* smoothstep(0.7f, 1.3f, g), math_utils.h:45-48: a constant divisor; g has no upper bound (the Doppler
+         * denominator can vanish), so the three-instruction divide is kept to dividends it is checked for */
+        const float grade_q = fabsf(shift_g) < 1.0e9f ? rrt_div_const(shift_g - 0.7f, 1.3f - 0.7f) : (shift_g - 0.7f) / (1.3f - 0.7f);
+        const float grade_t = fmin2(fmax2(grade_q, 0.0f), 1.0f);
+        const float grade = grade_t * grade_t * (3.0f - 2.0f * grade_t);
         ex += 0.60f * glow * lerp(1.2f, 0.8f, grade);
         ey += 0.65f * glow * lerp(0.8f, 1.1f, grade);
         ez += 0.80f * glow * lerp(0.6f, 1.4f, grade);

@@ -516,6 +516,7 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
     } else {
         int steps = i > a.max_steps ? i : a.max_steps;  /* if the loop runs out */
         float ys = 0.0f, hs = 0.0f;                     /* (1/r, 1/(2r)) estimate for the next loop-top radius; 0: none yet */
+        float hcp = 0.0f;                               /* 1/(2r) at the previous vacuum step's stage 3 (seed extrapolation) */
         for (int k = i; k < a.max_steps; ++k) {
             const v3 rel_p = p;                         /* p - MASS_POS, MASS_POS = 0 */
             const float r2 = dot(rel_p, rel_p);
@@ -531,14 +532,14 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
             if (r < kEventHorizon * 1.01f) { hit = true; acc.t = 0.0f; steps = k; break; }
 
             if (vacuum) {
-                integrate_rk4_lean<SPIN, true>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, y, hy, ys, hs);
+                integrate_rk4_lean<SPIN, true>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, y, hy, ys, hs, hcp);
             } else {
                 const bool near_bh = r < 18.0f;
                 const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
                 const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
                 float h, hh, h6;
                 zone_step(near_bh, in_disk, h, hh, h6);
-                integrate_rk4_lean<SPIN, false>(p, vel, h, hh, h6, a.drag_c, r2, r, y, hy, ys, hs);
+                integrate_rk4_lean<SPIN, false>(p, vel, h, hh, h6, a.drag_c, r2, r, y, hy, ys, hs, hcp);
                 if (MEDIA != 0 && (in_disk || in_cloud)) {
                     float d_disk, d_cloud;
                     media_densities<MEDIA == 2>(rel_p, a.time, in_disk, in_cloud, a.lut_acc, a.lut_dust, oob, d_disk, d_cloud);
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(kWGThreads, 8) __attribute__((amdgpu_num_sgpr(80)))
     bool overflow = false;                                        /* this lane stopped because the pool is full */
 
     constexpr bool LEAN = !FAST && RRT_MARCH_V2;               /* round 3's step (march_inline has the notes) */
-    float y_seed = 0.0f, h_seed = 0.0f;
+    float y_seed = 0.0f, h_seed = 0.0f, hc_prev = 0.0f;
     for (; i < a.max_steps; ++i) {
         const v3 rel_p = p;
         float r2, r, yv, hv = 0.0f;
@@ -755,8 +756,8 @@ __global__ __launch_bounds__(kWGThreads, 8) __attribute__((amdgpu_num_sgpr(80)))
         }
 
         if constexpr (LEAN) {
-            if (vacuum) integrate_rk4_lean<SPIN, true>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, yv, hv, y_seed, h_seed);
-            else integrate_rk4_lean<SPIN, false>(p, vel, h, hh, h6, a.drag_c, r2, r, yv, hv, y_seed, h_seed);
+            if (vacuum) integrate_rk4_lean<SPIN, true>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, yv, hv, y_seed, h_seed, hc_prev);
+            else integrate_rk4_lean<SPIN, false>(p, vel, h, hh, h6, a.drag_c, r2, r, yv, hv, y_seed, h_seed, hc_prev);
         } else march_step<SPIN, FAST>(p, vel, h, hh, h6, a.drag_c, r2, r, yv, y_seed);
 
         if (!vacuum && need) {                                                /* pre-step position, post-step velocity */
@@ -1143,6 +1144,40 @@ __global__ void k_selfcheck_div_tame(unsigned long long n, uint32_t seed, unsign
         float a = (k & 63) == 0 ? 0.0f : b * ratio;
         float q = rrt_div_tame(a, b), w = a / b;
         if (rrt_f2u(q) != rrt_f2u(w)) { ++bad; counters[1] = rrt_f2u(a); counters[2] = rrt_f2u(b); }
+    }
+    if (bad) atomicAdd(counters, (unsigned long long)bad);
+}
+
+/* rrt_div_const against IEEE `/` for the constants the media code divides by (smoothstep edges of densities.h:74-77,
+ * :124 and raymarcher.cu:97, the rim taper :27, ISCO_RADIUS, DISK_TEMP_REF): EVERY dividend whose bit pattern lies in
+ * [lo, hi), both signs, plus +0.  counters[0] += mismatches, [1]/[2] one failing case (dividend bits, constant index). */
+__global__ void k_selfcheck_div_const(uint32_t lo, uint32_t hi, unsigned long long* counters) {
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned bad = 0;
+    for (uint64_t b = (uint64_t)lo + idx; b < hi; b += stride) {
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            const float a = rrt_u2f((uint32_t)b | (sgn ? 0x80000000u : 0u));
+#define RRT_CHK(K, B) do { const float q = rrt_div_const(a, (B)), w = a / (B); \
+                           if (rrt_f2u(q) != rrt_f2u(w)) { ++bad; counters[1] = rrt_f2u(a); counters[2] = (K); } } while (0)
+            RRT_CHK(0, kDiskOut * 0.8f - kDiskOut);          /* -5 */
+            RRT_CHK(1, (kIsco + 5.0f) - kIsco);               /* 5 */
+            RRT_CHK(2, 0.8f - 0.4f);
+            RRT_CHK(3, kDiskOut - kDiskOut * 0.85f);          /* 3.75 */
+            RRT_CHK(4, kIsco);                                /* 10 */
+            RRT_CHK(5, kDiskTempRef);                         /* 1.5e7 */
+            RRT_CHK(6, 1.3f - 0.7f);
+#undef RRT_CHK
+        }
+    }
+    if (idx == 0) {
+        /* +0 dividends (x - e0 with x == e0): exact, sign included.  A -0 dividend would come back as +0 for a positive
+         * constant (the last fma adds +0 to it); none of the use sites can produce one -- every dividend is a
+         * difference with a non-zero literal, or a radius / temperature >= 1. */
+        const float z = 0.0f;
+        if (rrt_f2u(rrt_div_const(z, kDiskOut * 0.8f - kDiskOut)) != rrt_f2u(z / (kDiskOut * 0.8f - kDiskOut))) ++bad;
+        if (rrt_f2u(rrt_div_const(z, kIsco)) != rrt_f2u(z / kIsco)) ++bad;
+        if (rrt_f2u(rrt_div_const(z, 0.8f - 0.4f)) != rrt_f2u(z / (0.8f - 0.4f))) ++bad;
     }
     if (bad) atomicAdd(counters, (unsigned long long)bad);
 }
@@ -1793,6 +1828,13 @@ int rrt_unit_media_lut(int n, const float* p, float time, int table, float* out_
     const NoiseLut la = make_lut(nt.d_cells, nt.acc, nt.acc_families);
     const NoiseLut ld = make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust, nt.dust_families);
     return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_media_lut, g, b, 0, s, n, p, time, la, ld, out_disk, out_dust, d_counts); });
+}
+
+int rrt_selfcheck_div_const(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* st) {
+    if (!d_counters || lo_bits > hi_bits || hi_bits > 0x7f800000u) return RRT_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(k_selfcheck_div_const, dim3(4096), dim3(256), 0, static_cast<hipStream_t>(st), lo_bits, hi_bits, d_counters);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
 }
 
 int rrt_selfcheck_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* st) {

@@ -167,6 +167,14 @@ def test_bench_self_launches_its_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["comm_ranks"] == 2
     assert d["scaling"] == "strong" and d["value"] > 0
+    # round 3: the N > 1 line explains its own efficiency -- every rank's phase latencies (render | gather | assemble)
+    # and the same frames one at a time (latency-bound strong scaling) next to the pipelined value
+    mg = d["multi_gpu"]
+    ph, one = mg["phases"], mg["one_frame_at_a_time"]
+    assert len(ph["per_rank_render_ms"]) == 2 and all(v > 0 for v in ph["per_rank_render_ms"])
+    assert len(ph["per_rank_gather_ms"]) == 2 and ph["rank0_assemble_ms"] >= 0 and 0 < ph["render_balance_min_over_max"] <= 1
+    assert one["ms_per_step"] > 0 and one["value"] > 0 and len(one["per_rank_render_ms"]) == 2
+    assert mg["frames_in_flight"] == 3
 
 
 @pytest.mark.gpu

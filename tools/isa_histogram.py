@@ -74,6 +74,9 @@ def analyse(src, name, pretty):
             cur["comment"] += " " + l.strip()            # loop annotations follow the label on comment lines
         if cur is not None and t and not t.startswith("."):
             cur["ins"].append(t)
+            if re.match(r"s_c?branch", t):                   # a block ends at every branch (anonymous continuation block)
+                cur = {"label": cur["label"].split("+")[0] + "+%d" % (len(blocks)), "comment": cur["comment"], "ins": []}
+                blocks.append(cur)
     # outermost loop with the most instructions
     hdrs = collections.Counter()
     for b in blocks:
@@ -90,27 +93,50 @@ def analyse(src, name, pretty):
     # branches fall through (LLVM lays the likely successor out next and moves guarded / expect-false paths
     # out of line), unconditional branches are followed, until control returns to the header.
     order = {b["label"]: k for k, b in enumerate(blocks)}
-    path, seen = [], set()
-    cur_i = order[".L" + hdr]
-    while True:
-        b = blocks[cur_i]
-        if b["label"] in seen or b["label"] not in labels: break
-        seen.add(b["label"]); path.append(b)
-        last = b["ins"][-1] if b["ins"] else ""
-        m = re.match(r"s_branch\s+(\.LBB\d+_\d+)", last)
-        if m:
-            if m.group(1) == ".L" + hdr: break
-            cur_i = order[m.group(1)]
-        else:
-            cur_i += 1
-            if cur_i >= len(blocks): break
-    straight = path
-    sideb = [b for b in loop if b["label"] not in seen]
+    # Round 3: the loop has TWO straight paths -- the wave-uniform vacuum step (r >= 30 in every lane: h = 0.3 as literals,
+    # recognisable by the folded h/2 = 0x3e19999a) and the generic step.  The generic path is the fall-through walk; the
+    # vacuum path takes a conditional branch exactly when its target is the block that holds the vacuum step's literals.
+    VAC_LIT = "0x3e19999a"
+    vac_entry = set()
+    for k, b in enumerate(blocks):
+        if b in loop and not b["label"].count("+") and any(VAC_LIT in t for bb in blocks[k:k + 2] for t in bb["ins"][:4]):
+            vac_entry.add(b["label"])
+
+    def walk(take_vacuum):
+        path, seen = [], set()
+        cur_i = order[".L" + hdr]
+        while True:
+            b = blocks[cur_i]
+            if b["label"] in seen or b["label"] not in labels: break
+            seen.add(b["label"]); path.append(b)
+            last = b["ins"][-1] if b["ins"] else ""
+            m = re.match(r"s_branch\s+(\.LBB\d+_\d+)", last)
+            mc = re.match(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", last)
+            if m:
+                if m.group(1) == ".L" + hdr: break
+                cur_i = order[m.group(1)]
+            elif mc and take_vacuum and mc.group(1) in vac_entry:
+                cur_i = order[mc.group(1)]
+            elif mc and "execz" in last and cur_i + 1 < len(blocks) and any(
+                    re.match(r"v_(rsq|sqrt)_f32", t) for t in blocks[cur_i + 1]["ins"]):
+                cur_i = order[mc.group(1)]                   # an in-line rejected-seed fall-back: skipped when no lane needs it
+            else:
+                cur_i += 1
+                if cur_i >= len(blocks): break
+        return path, seen
+
+    straight, seen = walk(False)
+    vacuum, vseen = walk(True) if vac_entry else ([], set())
+    sideb = [b for b in loop if b["label"] not in seen and b["label"] not in vseen]
     print(f"== {pretty}")
     print(f"   registers: {res.get('NumVgprs')} VGPR, {res.get('TotalNumSgprs')} SGPR, occupancy {res.get('Occupancy')} waves/SIMD, "
           f"scratch {res.get('ScratchSize')} B, code {res.get('codeLenInByte')} B")
-    for title, bl in (("straight path of the march loop (one RK4 step" + (", media blocks included" if len(loop) > 60 else "") + ")", straight),
-                      ("blocks of the loop off that path (guarded fall-backs: a stage radius < 1, r2 not >= 1; lanes leaving)", sideb)):
+    sections = []
+    if vacuum and [b["label"] for b in vacuum] != [b["label"] for b in straight]:
+        sections.append(("VACUUM path of the march loop (every lane at r >= 30: one RK4 step, h = 0.3 folded, no zone tests)", vacuum))
+    sections.append(("generic path of the march loop (one RK4 step" + (", media blocks included" if len(loop) > 60 else "") + ")", straight))
+    sections.append(("blocks of the loop off those paths (guarded fall-backs: rejected seeds, a stage radius < 1; lanes leaving)", sideb))
+    for title, bl in sections:
         ins = [t.split()[0] for b in bl for t in b["ins"]]
         cls = collections.Counter(classify(o) for o in ins)
         ops = collections.Counter(o for o in ins)
@@ -119,7 +145,7 @@ def analyse(src, name, pretty):
         print(f"   {title}: {len(bl)} blocks, {len(ins)} instructions, {valu} VALU ({slots} issue slots counting half-rate ops twice)")
         for k, v in sorted(cls.items(), key=lambda kv: -kv[1]):
             print(f"      {k:34s} {v:5d}")
-        if bl is straight:
+        if bl is not sideb:
             print("      opcodes: " + ", ".join(f"{o} {n}" for o, n in ops.most_common(40)))
     print()
 
