@@ -66,6 +66,18 @@ std::vector<uint8_t> synthetic_sky(int w, int h, int seed) {
     return out;
 }
 
+// RRT_HEADLESS_TRACE=1: timestamped progress lines on stderr (set by the tests, so that a hang -- e.g. inside a
+// communicator bring-up on a sick node -- says where it sat when the harness kills the run)
+void trace(const char* what, int k = -1) {
+    static const bool on = getenv("RRT_HEADLESS_TRACE") != nullptr;
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (k >= 0) fprintf(stderr, "[rrt_headless %8.3f s] %s %d\n", t, what, k);
+    else fprintf(stderr, "[rrt_headless %8.3f s] %s\n", t, what);
+    fflush(stderr);
+}
+
 int fail(const char* what, int rc) {
     fprintf(stderr, "rrt_headless: %s: %s (%s)\n", what, rrt_status_string(rc), rrt_last_hip_error());
     return 1;
@@ -164,11 +176,14 @@ int main(int argc, char** argv) {
                 return fail("workspace", rc);
         }
     }
+    trace("per-device resources ready");
     if (collective) {
         std::vector<int> ids(gpus);
         std::vector<ncclComm_t> comms(gpus);
         for (int d = 0; d < gpus; ++d) ids[d] = d;
+        trace("ncclCommInitAll ...");
         NCCLCHK(ncclCommInitAll(comms.data(), gpus, ids.data()));
+        trace("ncclCommInitAll done");
         for (int d = 0; d < gpus; ++d) dev[d].comm = comms[d];
     }
     // device 0: gathered shards + assembled frame, per slot; pinned host frames for the sink
@@ -208,6 +223,7 @@ int main(int argc, char** argv) {
         float sim_t = 0.0f, path_t = 0.0f;
         rrt_recording_clock(k, fps, &sim_t, &path_t);
         if (path >= 0 && (rc = rrt_path_camera_at(path, path_t, &cam)) != RRT_OK) return fail("camera", rc);
+        trace("frame", k);
         // slot reuse: frame k-kSlots used the same buffers; its host copy must have been written out
         if (k > kSlots && deliver(slot)) return 1;
         // 0. noise tables: when the clock has left the window, every device builds the next one (after its frames in
@@ -269,6 +285,7 @@ int main(int argc, char** argv) {
         if (f) HIPCHK(hipMemcpyAsync(host[slot], frame[slot], frame_bytes, hipMemcpyDeviceToHost, dev[0].stream[slot]));
         HIPCHK(hipEventRecord(done[slot], dev[0].stream[slot]));
     }
+    trace("all frames enqueued; draining");
     // drain: the last min(frames, kSlots) frames, oldest first
     for (int k = frames - kSlots + 1; k <= frames; ++k)
         if (k >= 1 && deliver(k % kSlots)) return 1;

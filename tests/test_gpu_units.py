@@ -272,7 +272,7 @@ def test_fast_divide_is_correctly_rounded_on_march_operands(g):
     import torch
     from relativisticraytracer_amd import _lib
     cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
-    _lib.check(_lib.load().rrt_selfcheck_div(1 << 32, 12345, C.c_void_p(cnt.data_ptr()), None), "selfcheck_div")
+    _lib.check(_lib.load().rrt_selfcheck_div(1 << 35, 12345, C.c_void_p(cnt.data_ptr()), None), "selfcheck_div")
     torch.cuda.synchronize()
     assert int(cnt[0]) == 0, f"{int(cnt[0])} mismatches, e.g. {int(cnt[1]):#x} / {int(cnt[2]):#x}"
 

@@ -103,7 +103,12 @@ def test_cpp_driver_rccl_gather_path_writes_the_same_frames(tmp_path):
                   ["--force-collective", "--frames-in-flight", "1"], ["--force-collective", "--frames-in-flight", "2"],
                   ["--force-collective", "--frames-in-flight", "4"], ["--frames-in-flight", "4"]):
         out = tmp_path / "v.rgba"
-        r = subprocess.run([exe] + base + extra + ["--out", str(out)], capture_output=True, text=True, timeout=300)
+        try:
+            r = subprocess.run([exe] + base + extra + ["--out", str(out)], capture_output=True, text=True, timeout=240,
+                               env=dict(os.environ, RRT_HEADLESS_TRACE="1"))
+        except subprocess.TimeoutExpired as e:       # say where the driver sat (its timestamped trace), then fail
+            err = e.stderr.decode() if isinstance(e.stderr, bytes) else (e.stderr or "")
+            pytest.fail(f"rrt_headless {extra} hung; its trace:\n{err[-3000:]}")
         assert r.returncode == 0, r.stderr[-2000:]
         meta = json.loads(r.stdout.strip().splitlines()[-1])
         assert meta["n_gpus"] == 1 and meta["frames"] == 5
