@@ -469,6 +469,10 @@ __device__ __forceinline__ void zone_step(bool near_bh, bool in_disk, float& h, 
 #ifndef RRT_VACUUM_PATH
 #define RRT_VACUUM_PATH 1
 #endif
+#ifndef RRT_HORIZON_IN_GENERIC
+#define RRT_HORIZON_IN_GENERIC 0
+#endif
+
 /* r >= kVacuumR rules out the horizon test (r < 2.02) and every zone of raymarcher.cu:56-58 (near_bh r < 18, disk zone
  * r < 30, cloud zone r < 25): the step is h = STEP_SIZE_M with no media sample.  About nine steps in ten of the bench
  * frame are taken by wavefronts whose 64 rays are all out there. */
@@ -525,6 +529,16 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
             /* wave-uniform: every live lane holds an accepted radius >= kVacuumR (two compares, scalar logic) */
             const unsigned long long rej_mask = __builtin_amdgcn_ballot_w64(rejected);
             const bool vacuum = RRT_VACUUM_PATH && (rej_mask | __builtin_amdgcn_ballot_w64(!(r >= kVacuumR))) == 0ull;
+#if RRT_HORIZON_IN_GENERIC
+            if (vacuum) {
+                integrate_rk4_lean<SPIN, true>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, y, hy, ys, hs, hcp);
+            } else {
+                if (rej_mask != 0ull) {
+                    bool small;
+                    if (rejected) radius_fallback(r2, r, y, hy, small);
+                }
+                if (r < kEventHorizon * 1.01f) { hit = true; acc.t = 0.0f; steps = k; break; }
+#else
             if (!vacuum && rej_mask != 0ull) {
                 bool small;                             /* r < 1 ends the ray at the horizon test below */
                 if (rejected) radius_fallback(r2, r, y, hy, small);
@@ -534,6 +548,7 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
             if (vacuum) {
                 integrate_rk4_lean<SPIN, true>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, y, hy, ys, hs, hcp);
             } else {
+#endif
                 const bool near_bh = r < 18.0f;
                 const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
                 const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;

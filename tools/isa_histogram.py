@@ -87,7 +87,7 @@ def analyse(src, name, pretty):
     if not hdrs:
         print(f"{pretty}: no loop found"); return
     hdr = hdrs.most_common(1)[0][0]
-    loop = [b for b in blocks if b["label"] == ".L" + hdr or re.search(r"Header=%s Depth=1" % hdr, b["comment"])]
+    loop = [b for b in blocks if b["label"].split("+")[0] == ".L" + hdr or re.search(r"Header=%s Depth=1" % hdr, b["comment"])]
     labels = {b["label"] for b in loop}
     # STRAIGHT path = what a wavefront executes in a typical iteration: walk from the header, conditional
     # branches fall through (LLVM lays the likely successor out next and moves guarded / expect-false paths
@@ -99,8 +99,14 @@ def analyse(src, name, pretty):
     VAC_LIT = "0x3e19999a"
     vac_entry = set()
     for k, b in enumerate(blocks):
-        if b in loop and not b["label"].count("+") and any(VAC_LIT in t for bb in blocks[k:k + 2] for t in bb["ins"][:4]):
-            vac_entry.add(b["label"])
+        if b in loop and not b["label"].count("+"):
+            head = []
+            for bb in blocks[k:k + 3]:
+                if bb is not b and not bb["label"].startswith(b["label"] + "+"):
+                    break
+                head += bb["ins"]
+            if any(VAC_LIT in t for t in head[:8]):
+                vac_entry.add(b["label"])
 
     def walk(take_vacuum):
         path, seen = [], set()
