@@ -578,7 +578,11 @@ RRT_DEV v3 geodesic_acc_ng(v3 p, v3 v, float drag_c, float r2, float r, float y,
  * (loop top, stage 3), stage 2 from (the previous vacuum step's stage 3 ~ its stage 2 position, this loop top): the
  * error is y'' (h/2)^2 <= 2 (h / 2r)^2 = 5e-5 relative at r = 30, inside the one-iteration tolerance kSeedTol, and the
  * acceptance test catches everything else (first vacuum step after a step of another size: hc_prev belongs to
- * another spacing, the seed is rejected, the v_rsq fall-back runs once).  -2 instructions per vacuum step. */
+ * another spacing, the seed is rejected, the v_rsq fall-back runs once).  -2 instructions per vacuum step.
+ * Sign: the acceptance test is even in the seed (a seed of MINUS the reciprocal root converges to minus the root with a
+ * zero residual), so seeds must be positive by provenance -- they are: every h is either the v_rsq fall-back's or
+ * h0 (1 + r) of an accepted root with |r| <= 9e-3, i.e. positive by induction, and an extrapolated 2 h_a - h_b of two
+ * such values could only be negative if the radius had tripled within half a vacuum step (0.15 |v| at r >= 30). */
 template <bool SPIN, bool VAC>
 RRT_DEV void integrate_rk4_lean(v3& p, v3& v, float h_in, float hh_in, float h6_in, float drag_c,
                                 float r2, float r, float y, float hy, float& y_next, float& h_next, float& hc_prev) {
@@ -743,6 +747,7 @@ RRT_DEV float noise3d_sel(v3 p, const NoiseLut& L, bool from_table, unsigned* oo
 #ifndef RRT_LUT_PAIRS
 #define RRT_LUT_PAIRS 1
 #endif
+
 RRT_DEV void noise3d_lut_pair(const NoiseLut& L, v3 p0, v3 p1, unsigned* oob, float& n0, float& n1) {
     if (RRT_PROBE & 8) { n0 = 0.45f + 0.01f * p0.x; n1 = 0.45f + 0.01f * p1.x; return; }
     const LutTap a = lut_fetch(L, p0, oob);
