@@ -127,11 +127,58 @@ RRT_FN float rrt_pow_pos(float x, float y) {
 }
 
 /*
+ * Round 3: the path's other exponents are fifths and -3/4 (0.2, 0.4, 1.2, 1.6: densities.h:34,58,80, raymarcher.cu:82,93;
+ * -0.75: densities.h:14) -- roots, not general powers.  x^(k/5) = fifth root of x^k, and a fifth root divides the
+ * relative error of its argument by five, so a few multiplies plus ONE accurate root beat exp(y log x) on both counts:
+ * ~30 instructions instead of ~85, and 1.0-1.9 ulp instead of 2 (measured against float64 over [1e-4, 1e3],
+ * tests/test_portable_math.py).  Division-free, no table, integer seed:
+ *   rrt_root5:     z ~ x^(-1/5) from the bit trick (3 % off), three Newton steps z <- z (1.2 - 0.2 x z^5) (quadratic),
+ *                  w = x z^4, then one Newton step on w^5 = x whose residual w^4*w - x is formed in one fma:
+ *                  w - (w^5 - x) z^4 / 5.  <= 1 ulp over the whole normal range.
+ *   rrt_pow_m075:  y ~ x^(-3/4) from the bit trick (4 % off), two steps y <- y (1.25 - 0.25 x^3 y^4), then the same
+ *                  kind of fma-residual correction.  <= 1.3 ulp.
+ * Both need x normal and the intermediate powers in range; rrt_powf checks the exponent field and sends anything else
+ * (and every other exponent) through rrt_pow_pos.
+ */
+RRT_FN float rrt_root5(float x) {                      /* x normal, > 0 */
+    float z = rrt_u2f(0x4c2ba000u - rrt_f2u(x) / 5u);
+    const float x02 = x * 0.2f;
+    for (int k = 0; k < 3; ++k) {
+        const float z2 = z * z, z4 = z2 * z2, z5 = z4 * z;
+        z = z * rrt_fma(-x02, z5, 1.2f);
+    }
+    const float z2 = z * z, z4 = z2 * z2;
+    const float w = x * z4;
+    const float w2 = w * w, w4 = w2 * w2;
+    const float e = rrt_fma(w4, w, -x);
+    return rrt_fma(-e, z4 * 0.2f, w);
+}
+
+RRT_FN float rrt_pow_m075(float x) {                   /* x in 2^[-20, 20] */
+    const uint32_t i = rrt_f2u(x);
+    float y = rrt_u2f(0x6f150000u - (i - (i >> 2)));
+    const float u = (x * x) * x;
+    const float u025 = u * 0.25f;
+    for (int k = 0; k < 2; ++k) {
+        const float y2 = y * y, y4 = y2 * y2;
+        y = y * rrt_fma(-u025, y4, 1.25f);
+    }
+    const float y2 = y * y, y4 = y2 * y2;
+    const float r = rrt_fma(-u, y4, 1.0f);
+    return rrt_fma(y * 0.25f, r, y);
+}
+
+/* is x a normal float with unbiased exponent in [lo, hi)?  (one subtract + one unsigned compare) */
+RRT_FN int rrt_exp_in(float x, int lo, int hi) {
+    return (rrt_f2u(x) - ((uint32_t)(lo + 127) << 23)) < ((uint32_t)(hi - lo) << 23);
+}
+
+/*
  * powf as the path uses it: base >= 0, finite, and the exponent is one of a
  * handful of literals (geodesics.h:17, densities.h:14,32,34,41,58,80,89,125,
  * raymarcher.cu:79,80,82,93).  Exponents with an exact radical form are
- * evaluated through sqrt/multiplies (<= 2 ulp, usually correctly rounded);
- * everything else goes through rrt_pow_pos.  Negative bases do not occur.
+ * evaluated through sqrt/multiplies (<= 2 ulp, usually correctly rounded), fifths and
+ * -3/4 through the roots above; everything else goes through rrt_pow_pos.  Negative bases do not occur.
  */
 RRT_FN float rrt_powf(float x, float y) {
     if (x != x) return x;
@@ -140,6 +187,24 @@ RRT_FN float rrt_powf(float x, float y) {
     if (y == 0.5f) return rrt_sqrt(x);
     if (y == 1.5f) return x * rrt_sqrt(x);
     if (y == 4.0f) { float x2 = x * x; return x2 * x2; }
+    if (y == 0.2f && rrt_exp_in(x, -20, 20)) return rrt_root5(x);
+    if (y == 0.4f && rrt_exp_in(x, -20, 20)) return rrt_root5(x * x);
+    /* The literals 1.2f and 1.6f are not 6/5 and 8/5: they exceed them by d = 4.77e-8 and 2.38e-8, and the reference's
+     * powf raises to the literal.  x^d = 1 + d ln x to first order, with ln x good to 0.06 from the exponent and
+     * mantissa bits read as an integer; applied to the root's ARGUMENT (as 1 + 5 d ln x, so that its rounding is divided
+     * by five too) it keeps the result within 2 ulp of powf(x, 1.6f) for small x as well (without it: up to 2 ulp
+     * more at x = 1e-4).  0.2f and 0.4f are off by 3e-9 and 6e-9: nothing to correct inside 2^[-20, 20]. */
+    if (y == 1.2f && rrt_exp_in(x, -20, 20)) {
+        const float x3 = (x * x) * x, x6 = x3 * x3;
+        const float lnx = (float)(int32_t)(rrt_f2u(x) - 0x3f800000u) * 8.26295829e-8f;      /* ln 2 / 2^23 */
+        return rrt_root5(rrt_fma(x6 * 2.38418579e-7f, lnx, x6));                            /* 5 * 4.76837158e-8 */
+    }
+    if (y == 1.6f && rrt_exp_in(x, -15, 15)) {
+        const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+        const float lnx = (float)(int32_t)(rrt_f2u(x) - 0x3f800000u) * 8.26295829e-8f;
+        return rrt_root5(rrt_fma(x8 * 1.19209290e-7f, lnx, x8));                            /* 5 * 2.38418579e-8 */
+    }
+    if (y == -0.75f && rrt_exp_in(x, -20, 20)) return rrt_pow_m075(x);
     return rrt_pow_pos(x, y);
 }
 
