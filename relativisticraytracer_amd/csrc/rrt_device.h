@@ -48,6 +48,10 @@ __device__ __forceinline__ float rrt_div_core(float a, float b, float seed) {
 }
 __device__ __forceinline__ float rrt_div_tame(float a, float b) { return rrt_div_core(a, b, __builtin_amdgcn_rcpf(b)); }
 #define RRT_MATH_TAME_DIV(a, b) rrt_div_tame((a), (b))
+/* y * 2^k, the tail of rrt_expf: one v_ldexp_f32 instead of two multiplies and the integer work that builds their
+ * factors -- the same function (rrt_math.h: rrt_scale2), checked bit for bit down into the subnormal results by the
+ * math-function unit tests. */
+#define RRT_MATH_SCALE2(y, k) __builtin_ldexpf((y), (k))
 #else
 __host__ __device__ static inline float rrt_div_tame(float a, float b) { return a / b; }   /* host pass: never executed */
 #endif

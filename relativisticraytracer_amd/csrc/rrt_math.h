@@ -24,8 +24,14 @@
  * against glibc in tests/test_portable_math.py.
  *
  * Algorithms: argument reductions and minimax polynomials follow the published
- * Cephes single-precision library (S. Moshier); powf is exp(y*log x) with the
- * logarithm carried as an unevaluated hi+lo pair.
+ * Cephes single-precision library (S. Moshier); the general powf is exp(y*log x)
+ * with the logarithm carried as an unevaluated hi+lo pair.  The five rational
+ * exponents the path's call sites pass as literals (0.2f 0.4f 1.2f 1.6f -0.75f)
+ * are served by division-free Newton roots instead (rrt_root5 / rrt_pow_m075
+ * below: a fifth root of x, x^2, x^6 or x^8, the last two corrected to first
+ * order for the literals not being 6/5 and 8/5) -- about a third of the
+ * instructions and 0.9-1.9 ulp against float64 on the path's ranges; arguments
+ * outside the windows those forms are proven on take the general route.
  */
 #ifndef RRT_MATH_H
 #define RRT_MATH_H
@@ -44,8 +50,8 @@ RRT_FN float rrt_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c)
 RRT_FN float rrt_sqrt(float x) { return __builtin_sqrtf(x); }
 RRT_FN float rrt_abs(float x) { return __builtin_fabsf(x); }
 
-/* Hook for the two divisions below whose operands are tame by construction (the denominator lies in [1.4, 3.5],
- * the quotient in (-1, 1.1]): the gfx950 kernels substitute a bare reciprocal + Markstein sequence that gives the
+/* Hook for the division of the general powf below, whose operands are tame by construction (the denominator lies
+ * in [1.70, 2.42], the quotient in (0.41, 0.59)): the gfx950 kernels substitute a bare reciprocal + Markstein sequence that gives the
  * IEEE quotient bit for bit on such operands (csrc/rrt_device.h: rrt_div_tame) but skips hipcc's range scaling;
  * every other translation unit (the CPU oracle) uses the plain `/`. */
 #ifndef RRT_MATH_TAME_DIV
@@ -59,6 +65,17 @@ RRT_FN float rrt_abs(float x) { return __builtin_fabsf(x); }
 
 /* 2^k for k in [-126, 127] */
 RRT_FN float rrt_pow2i(int k) { return rrt_u2f((uint32_t)(k + 127) << 23); }
+
+/* y * 2^k for y in [0.5, 2), k in [-152, 129]: two exact-or-once-rounded multiplies (the first product is a normal
+ * number, so only the second can round -- once, like ldexpf, into the subnormals or to infinity).  The gfx950 kernels
+ * substitute the one-instruction v_ldexp_f32 (csrc/rrt_device.h), which is the same function. */
+RRT_FN float rrt_scale2(float y, int k) {
+    const int k1 = k >> 1, k2 = k - k1;
+    return (y * rrt_pow2i(k1)) * rrt_pow2i(k2);
+}
+#ifndef RRT_MATH_SCALE2
+#define RRT_MATH_SCALE2(y, k) rrt_scale2((y), (k))
+#endif
 
 /* exp(hi + lo) for |lo| << |hi|; shared tail of expf and powf. */
 RRT_FN float rrt_exp_hl(float hi, float lo) {
@@ -77,10 +94,7 @@ RRT_FN float rrt_exp_hl(float hi, float lo) {
     p = rrt_fma(p, r, 1.6666665459E-1f);
     p = rrt_fma(p, r, 5.0000001201E-1f);
     float y = rrt_fma(p, z, r) + 1.0f;
-    int ki = (int)k;
-    int k1 = ki >> 1;
-    int k2 = ki - k1;
-    return (y * rrt_pow2i(k1)) * rrt_pow2i(k2);
+    return RRT_MATH_SCALE2(y, (int)k);
 }
 
 RRT_FN float rrt_expf(float x) {
@@ -243,34 +257,35 @@ RRT_FN void rrt_sincosf(float x, float* sn, float* cs) {
 RRT_FN float rrt_sinf(float x) { float s, c; rrt_sincosf(x, &s, &c); return s; }
 RRT_FN float rrt_cosf(float x) { float s, c; rrt_sincosf(x, &s, &c); return c; }
 
-/* atan for any finite x */
-RRT_FN float rrt_atanf(float x) {
-    float ax = rrt_abs(x);
-    float y0, t;
-    if (ax > 2.414213562373095f) { y0 = 1.5707963267948966f; t = -1.0f / ax; }
-    else if (ax > 0.4142135623730950f) { y0 = 0.7853981633974483f; t = RRT_MATH_TAME_DIV(ax - 1.0f, ax + 1.0f); }
-    else { y0 = 0.0f; t = ax; }
-    float z = t * t;
+/*
+ * atan2 with ONE division (round 3).  With mx = max(|x|, |y|), mn = min(|x|, |y|) the angle of the first-octant
+ * point (mx, mn) is atan(mn / mx) in [0, pi/4]; Cephes' reduction at tan(pi/8) -- atan(s) = pi/4 + atan((s - 1)/(s + 1))
+ * for s > 0.4142 -- is applied to numerator and denominator BEFORE they are divided ((mn - mx) / (mn + mx)), so the
+ * quotient y/x, the second quotient of the reduction and the -1/s of the steep case (three IEEE divisions on three
+ * divergent branches in the textbook form) collapse into a single t = num / den with |t| <= tan(pi/8), followed by
+ * Cephes' degree-4 minimax in t^2.  The octant is put back by pi/2 - r (|y| > |x|), pi - r (x < 0) and the sign of y.
+ * <= 3 ulp against float64 on the path's arguments (tests/test_portable_math.py; the form it replaces: <= 4).
+ * Axis cases as before: atan2(+-0, x > 0) = 0, atan2(+-0, x < 0) = +pi, atan2(y, 0) = +-pi/2, atan2(0, 0) = 0.
+ */
+RRT_FN float rrt_atan2f(float y, float x) {
+    if (x != x || y != y) return x + y;
+    const float ax = rrt_abs(x), ay = rrt_abs(y);
+    const int steep = ay > ax;
+    const float mx = steep ? ay : ax, mn = steep ? ax : ay;
+    if (mx == 0.0f) return 0.0f;
+    const int fold = mn > 0.4142135623730950f * mx;
+    const float num = fold ? mn - mx : mn;
+    const float den = fold ? mn + mx : mx;
+    const float t = num / den;
+    const float z = t * t;
     float p = 8.05374449538e-2f;
     p = rrt_fma(p, z, -1.38776856032E-1f);
     p = rrt_fma(p, z, 1.99777106478E-1f);
     p = rrt_fma(p, z, -3.33329491539E-1f);
-    float r = y0 + rrt_fma(p * z, t, t);
-    return (x < 0.0f) ? -r : r;
-}
-
-RRT_FN float rrt_atan2f(float y, float x) {
-    const float PI_F = 3.14159265358979323846f;
-    const float PIO2_F = 1.5707963267948966f;
-    if (x != x || y != y) return x + y;
-    if (x == 0.0f) {
-        if (y == 0.0f) return 0.0f;
-        return (y < 0.0f) ? -PIO2_F : PIO2_F;
-    }
-    if (y == 0.0f) return (x < 0.0f) ? PI_F : 0.0f;
-    float w = 0.0f;
-    if (x < 0.0f) w = (y < 0.0f) ? -PI_F : PI_F;
-    return w + rrt_atanf(y / x);
+    float r = (fold ? 0.7853981633974483f : 0.0f) + rrt_fma(p * z, t, t);
+    if (steep) r = 1.5707963267948966f - r;
+    if (x < 0.0f) r = 3.14159265358979323846f - r;
+    return (y < 0.0f) ? -r : r;
 }
 
 /* asin for |x| <= 1 */

@@ -73,6 +73,10 @@ def test_portable_math_bitexact(g, po):
         (3, rng.uniform(-400, 400, n), None),
         (4, rng.uniform(-300, 300, n), rng.uniform(-300, 300, n)),
         (5, rng.uniform(-1, 1, n), None),
+        (0, rng.uniform(80, 92, n), None),                                        # up to and past the overflow of the 2^k tail (v_ldexp_f32)
+        (1, np.exp(rng.uniform(np.log(1e-30), np.log(1e30), n)), rng.choice([0.4, 1.6, 0.2, 1.2, -0.75, 2.5, -3.0, 7.0], n)),
+        (4, rng.choice([0.0, -0.0, 1e-30, -1e-30, 1.0, -3.0, 1e30], n), rng.choice([0.0, -0.0, 1e-30, -1e-30, 2.0, -5.0, 1e30], n)),   # axes, tiny, huge
+        (4, rng.uniform(-25, 25, n) * rng.choice([1.0, 1e-5, 1e-12], n), rng.uniform(-25, 25, n)),      # the disk's azimuths, incl. next to the axes
     ]
     for fn, a, b in cases:
         a = a.astype(np.float32); b = (b if b is not None else np.zeros(n)).astype(np.float32)

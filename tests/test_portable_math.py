@@ -71,13 +71,21 @@ def test_atan2_asin(po):
     rng = np.random.default_rng(2)
     y = rng.uniform(-300, 300, 400_000).astype(np.float32); x = rng.uniform(-300, 300, 400_000).astype(np.float32)
     got = po.math_fn(4, po.MATH_PORTABLE, y, x)
-    assert ulp_diff(got, np.arctan2(y.astype(np.float64), x.astype(np.float64))).max() <= 4.0
+    assert ulp_diff(got, np.arctan2(y.astype(np.float64), x.astype(np.float64))).max() <= 3.2      # measured 2.9 (one-division form, round 3)
+    th = rng.uniform(-np.pi, np.pi, 400_000); rr = rng.uniform(10, 25, 400_000)       # the disk's azimuths, incl. near the axes
+    for squash in (1.0, 1e-4):
+        y = (rr * np.sin(th) * squash).astype(np.float32); x = (rr * np.cos(th)).astype(np.float32)
+        got = po.math_fn(4, po.MATH_PORTABLE, y, x)
+        assert ulp_diff(got, np.arctan2(y.astype(np.float64), x.astype(np.float64))).max() <= 3.2
     a = np.concatenate([_dense(-1, 1), np.float32([1, -1, 0, 1e-5, -1e-5])])
     got = po.math_fn(5, po.MATH_PORTABLE, a)
     assert ulp_diff(got, np.arcsin(a.astype(np.float64))).max() <= 3.0
     # axis cases of atan2
     got = po.math_fn(4, po.MATH_PORTABLE, np.float32([0, 1, -1, 0]), np.float32([1, 0, 0, -1]))
     assert np.allclose(got, [0, np.pi / 2, -np.pi / 2, np.pi], atol=3e-7)
+    got = po.math_fn(4, po.MATH_PORTABLE, np.float32([-0.0, 0, -0.0, 5, -5]), np.float32([-1, 0, 0, np.inf, np.inf]))
+    assert np.array_equal(got, np.float32([np.pi, 0, 0, 0, 0]))
+    assert np.isnan(po.math_fn(4, po.MATH_PORTABLE, np.float32([np.nan, 1]), np.float32([1, np.nan]))).all()
 
 
 def test_libm_mode_is_glibc(po):
