@@ -42,7 +42,21 @@ def main(argv=None):
     ap.add_argument("--out", default=None, help="x.rgba (raw, bottom-up) | dir/ (PPM per frame) | x.mp4 (needs ffmpeg)")
     args = ap.parse_args(argv)
 
+    t_start = time.perf_counter()
+
+    def trace(what):        # RRT_HEADLESS_TRACE=1: where the start-up time goes (stderr), as in csrc/rrt_headless.cpp
+        dest = os.environ.get("RRT_HEADLESS_TRACE")        # "1": stderr; anything else: a file to append to
+        if dest:
+            line = f"[headless.py pid {os.getpid()} +{time.perf_counter() - t_start:7.2f}s] {what}"
+            if dest == "1":
+                print(line, file=sys.stderr, flush=True)
+            else:
+                with open(dest, "a") as fh:
+                    print(line, file=fh)
+
+    trace("importing torch")
     import torch
+    trace("torch imported")
     import relativisticraytracer_amd as rrt
     from relativisticraytracer_amd import camera_paths, sharding, sinks
     from relativisticraytracer_amd.sky import load_sky, synthetic_sky
@@ -54,6 +68,7 @@ def main(argv=None):
     backend = os.environ.get("RRT_DIST_BACKEND", "nccl")        # "gloo": rehearsal on fewer GPUs than ranks
     if backend == "gloo":
         local_rank %= max(1, torch.cuda.device_count())
+    trace("GPU visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -63,6 +78,7 @@ def main(argv=None):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    trace("process group ready" if world > 1 else "single rank")
     w, h = args.width, args.height
     tex = rrt.SkyTexture(load_sky(args.sky) if args.sky else synthetic_sky())
     fx = rrt.CameraEffects(useChromaticAberration=bool(args.all_effects))
@@ -104,6 +120,7 @@ def main(argv=None):
         sink.write(host.numpy().reshape(h, w, 4))
 
     torch.cuda.synchronize()
+    trace("sky, pools, sink ready; first frame")
     t0 = time.perf_counter()
     for k in range(1, args.frames + 1):
         sim_t, path_t = camera_paths.recording_clock(k, args.fps)
@@ -118,6 +135,7 @@ def main(argv=None):
         if sink:
             deliver(frame)
     torch.cuda.synchronize()
+    trace("frames done")
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
