@@ -640,6 +640,11 @@ __device__ __forceinline__ unsigned wave_index() {
 template <bool SPIN, int MEDIA, bool DEBUG, bool FAST>
 __global__ __launch_bounds__(kWGThreads, (MEDIA != 0 && !DEBUG ? RRT_MEDIA_WAVES : 1))      /* 2nd: minimum waves per SIMD */
 void raymarch_pixels(const FrameArgs a) {
+#if defined(RRT_OCC_PROBE_LDS)      /* dev probe: cap the occupancy of the kernel WITHOUT media code through its LDS footprint (8192 B per one-wave
+                                     * workgroup = 20 workgroups per CU = 5 waves per SIMD): what the march loses at the media kernels' occupancy */
+    __shared__ volatile int occ_pad[RRT_OCC_PROBE_LDS / 4];
+    if (MEDIA == 0) occ_pad[threadIdx.x] = 0;
+#endif
     int x, y, out_row;
     if (!lane_pixel(a, x, y, out_row)) return;
     float uvx, uvy;
