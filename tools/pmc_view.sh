@@ -9,7 +9,7 @@ import csv, glob, sys
 f = glob.glob("/tmp/pmcv/**/*counter_collection.csv", recursive=True)[0]
 acc = {}
 for r in csv.DictReader(open(f)):
-    if int(r["Grid_Size"]) < 1000000: continue
+    if int(r["Grid_Size"]) < 1000000 or "raymarch_pixels" not in r["Kernel_Name"]: continue
     acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 for k in sorted(acc): print(f"{sys.argv[1]:10s} vol={sys.argv[2]} {k:28s} {sum(acc[k])/len(acc[k]):.6g}")
 PY
