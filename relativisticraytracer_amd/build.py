@@ -25,8 +25,13 @@ HEADERS = [os.path.join(CSRC, "rrt_device.h"), os.path.join(CSRC, "rrt_math.h"),
 # v_mov shuffles; measured 8 % slower than scalar VALU on the march loop (profiles/README.md).
 # -mllvm -enable-post-misched=false: the post-RA machine scheduler's reordering costs the kernels that carry the
 # volumetric code 3-4 % (4K bench frame 44.6 -> 43.3 ms, same bytes; profiles/README.md); the bare march is unaffected.
+# -mllvm -amdgpu-sched-strategy=max-ilp (round 3): inside the short guarded blocks the step is now made of, the ILP-first
+# pre-RA strategy costs registers the bare march can spare (55 -> 73 VGPRs; it keeps its rate down to 4 waves per SIMD) and buys
+# 1.2-1.4 % on the kernels without media code, 3 % in fast mode, 0.3-0.9 % with media (profiles/r03_sched_strategy_ab.txt).
+# Round 2 measured the same flag 25 % SLOWER on the then monolithic step -- it interleaved the four stages.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-fno-gpu-rdc", "-fno-slp-vectorize", "-mllvm", "-enable-post-misched=false",
+               "-mllvm", "-amdgpu-sched-strategy=max-ilp",
                "-Wall", "-Wno-unused-function"]
 
 
@@ -71,8 +76,15 @@ def build_variant(name, extra_flags=()):
     if not os.path.exists(compat_obj):
         subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-c", COMPAT_SRC, "-o", compat_obj], check=True)
     obj = os.path.join(vdir, name + ".o")
-    subprocess.run([hipcc_path()] + [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + ["-c"] + SOURCES + ["-o", obj],
-                   check=True, cwd=vdir)
+    base = [f for f in HIPCC_FLAGS if f != "-shared"]
+    for d in [f[len("--drop="):] for f in extra_flags if f.startswith("--drop=")]:      # --drop=<flag>: build WITHOUT a shipped flag
+        i = base.index(d)
+        if i > 0 and base[i - 1] == "-mllvm":
+            del base[i - 1:i + 1]
+        else:
+            del base[i]
+    extra_flags = [f for f in extra_flags if not f.startswith("--drop=")]
+    subprocess.run([hipcc_path()] + base + list(extra_flags) + ["-c"] + SOURCES + ["-o", obj], check=True, cwd=vdir)
     out = os.path.join(vdir, name + ".so")
     subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", obj, compat_obj, "-o", out],
                    check=True, cwd=vdir)

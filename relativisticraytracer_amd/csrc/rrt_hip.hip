@@ -632,13 +632,12 @@ __device__ __forceinline__ unsigned wave_index() {
 
 /* Single-kernel path: one ray per lane, media sampled in line (reference raymarch_kernel,
  * src/raymarcher.cu:15-174). */
-/* Register budgets: 64 VGPRs = 8 waves per SIMD for the bare march; 80 = 6 for the kernels that carry the media code.
- * Left alone they take ~95 (5 waves); since the rrt_math.h rewrite they fit 80 without a spill, and the table-served
- * media code gains 0.2-0.7 % from the sixth wave (profiles/r03_media_waves_ab.txt: 4 waves +3.6 % on the skimmer view,
- * 5 the baseline, 6 -0.7 %, 7 = 72 VGPRs with ten spills -1.2 % there but nothing elsewhere).  The bare march does not
- * care (r03_march_occupancy_probe.txt). */
+/* Register budgets.  The bare march takes what the ILP-first scheduler wants (73 VGPRs = 7 waves per SIMD; it keeps its
+ * rate down to 4: profiles/r03_march_occupancy_probe.txt).  The kernels that carry the media code are held to 96 = 5 waves:
+ * the table-served media code loses 3.6 % at 4 waves and gains 0.7 % at 6 (80 VGPRs: no spill under the default scheduler
+ * since the rrt_math.h rewrite, eight spills under max-ilp, which is worth more: r03_media_waves_ab.txt, r03_sched_strategy_ab.txt). */
 #ifndef RRT_MEDIA_WAVES
-#define RRT_MEDIA_WAVES 6
+#define RRT_MEDIA_WAVES 5
 #endif
 template <bool SPIN, int MEDIA, bool DEBUG, bool FAST>
 __global__ __launch_bounds__(kWGThreads, (MEDIA != 0 && !DEBUG ? RRT_MEDIA_WAVES : 1))      /* 2nd: minimum waves per SIMD */
