@@ -738,6 +738,18 @@ RRT_DEV float disk_temperature(float r) { return disk_temperature_t<false>(r); }
 #ifndef RRT_PROBE
 #define RRT_PROBE 0
 #endif
+/* unroll factors of the media loops (1 = rolled, the shipped form; A/B builds override them) */
+#define RRT_PRAGMA_STR(x) _Pragma(#x)
+#define RRT_PRAGMA_UNROLL(n) RRT_PRAGMA_STR(unroll n)
+#ifndef RRT_WARP_UNROLL
+#define RRT_WARP_UNROLL 1
+#endif
+#ifndef RRT_ACC_UNROLL
+#define RRT_ACC_UNROLL 1
+#endif
+#ifndef RRT_RIDGE_UNROLL
+#define RRT_RIDGE_UNROLL 1
+#endif
 /* one noise3D evaluation, from the table when the wave-uniform switch says so */
 template <bool LUT>
 RRT_DEV float noise3d_sel(v3 p, const NoiseLut& L, bool from_table, unsigned* oob) {
@@ -881,7 +893,7 @@ RRT_DEV float accretion_density_at(v3 p, float time, DiskPoint& dp, const NoiseL
         from_table &= L.families;
     }
     float n = 0.0f, amp = 0.5f;                         /* fbm(at, 5), math_utils.h:112-121 */
-#pragma unroll 1
+RRT_PRAGMA_UNROLL(RRT_ACC_UNROLL)
     for (int o = 0; o < 5; ++o) {
         if (LUT && RRT_LUT_PAIRS && ((from_table >> o) & 3u) == 3u) {     /* this octave and the next: one round trip */
             const v3 at1 = mk(at.x * 2.05f + 10.0f, at.y * 2.05f + 10.0f, at.z * 2.05f + 10.0f);
@@ -951,7 +963,7 @@ RRT_DEV float dust_density_at(v3 p, float time, DiskPoint& dp, const NoiseLut& L
      * (c + 0 for the first: adding +0.0f changes no result, see noise3d) */
     const v3 c15 = mul(sc, 0.15f);
     float wx = 0.f, wy = 0.f, wz = 0.f;
-#pragma unroll 1
+RRT_PRAGMA_UNROLL(RRT_WARP_UNROLL)
     for (int k = 0; k < 3; ++k) {
         const float ox = k == 0 ? 0.0f : (k == 1 ? 1.0f : 4.0f);
         const float oy = k == 0 ? 0.0f : (k == 1 ? 2.0f : 5.0f);
@@ -962,7 +974,7 @@ RRT_DEV float dust_density_at(v3 p, float time, DiskPoint& dp, const NoiseLut& L
     /* second warp, :101-106: offsets (0,0,0), (2,1,0), (0,3,1) on (sc + 3*w1)*0.4 */
     const v3 c40 = mul(add(sc, mul(mk(wx, wy, wz), 3.0f)), 0.4f);
     float vx = 0.f, vy = 0.f, vz = 0.f;
-#pragma unroll 1
+RRT_PRAGMA_UNROLL(RRT_WARP_UNROLL)
     for (int k = 0; k < 3; ++k) {
         const float ox = k == 1 ? 2.0f : 0.0f;
         const float oy = k == 0 ? 0.0f : (k == 1 ? 1.0f : 3.0f);
@@ -974,7 +986,7 @@ RRT_DEV float dust_density_at(v3 p, float time, DiskPoint& dp, const NoiseLut& L
 
     float n = 0.0f, amp = 1.0f, freq = 1.0f;                       /* ridged sum, :111-120 */
     const unsigned ridge_bits = (from_table >> 4) & ((1u << kLutRidgeOctaves) - 1u);
-#pragma unroll 1
+RRT_PRAGMA_UNROLL(RRT_RIDGE_UNROLL)
     for (int k = 0; k < 5; ++k) {
         /* Exact early-out (round 3, render kernels only): every ridge term is <= amp (1 - |2 noise - 1| <= 1), so the
          * finished sum is <= n + 2 amp (the remaining amplitudes amp, amp/2 ... add up to < 2 amp; the float sum of at
