@@ -363,10 +363,13 @@ def main():
         ht = 14.0
         hbuf = torch.zeros(h * w * 4, dtype=torch.uint8, device=dev)
         res = {}
-        for tag, tab in (("arithmetic_noise", 0), ("noise_table", ntab.id if ntab else 0)):
-            if tag == "noise_table" and not ntab:
+        horder = rrt.TileOrder()        # "noise_table_cost_ordered": rrt_tile_order, each frame dispatched longest-first by the previous one's costs
+        for tag, tab, oid in (("arithmetic_noise", 0, 0), ("noise_table", ntab.id if ntab else 0, 0),
+                              ("noise_table_cost_ordered", ntab.id if ntab else 0, horder.id)):
+            if tag != "arithmetic_noise" and not ntab:
                 continue
-            hp = rrt.RenderParams(spin=args.spin, volumetrics=1, noise_table=tab)
+            hp = rrt.RenderParams(spin=args.spin, volumetrics=1, noise_table=tab, tile_order=oid)
+            rrt.launch_raymarch(hbuf, w, h, ht, hcam, tex, fx, hp)
             rrt.launch_raymarch(hbuf, w, h, ht, hcam, tex, fx, hp)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -375,7 +378,11 @@ def main():
             torch.cuda.synchronize()
             hms = (time.perf_counter() - t1) / max(2, args.steps // 2) * 1e3
             res[tag] = {"ms_per_step": round(hms, 3), "Mrays_per_s": round(w * h / hms / 1e3, 3), "fps": round(1e3 / hms, 3)}
+        horder.destroy()
         heavy = {"view": "Horizon Skimmer key (4.2, 0.6, 4.2) yaw -90 pitch -5.7, t=14.0, same size / spin / effects", **res}
+        if "noise_table_cost_ordered" in heavy:
+            heavy["noise_table_cost_ordered"]["note"] = ("rrt_params.tile_order: wave tiles dispatched longest-first, costs measured by the previous "
+                                                         "launch (the sort behind every frame is inside the time); same bytes")
 
     if rank == 0:
         rays = w * h
@@ -419,7 +426,7 @@ def main():
                                  time_=14.0)
             heavy["per_ray_means"] = {k: round(v, 2) for k, v in hm.items()}
             heavy["ops_per_ray"] = round(ops_per_ray(hm["steps"], hm["n_noise"], hm["n_dens"], hm["n_samples"]), 1)
-            for tag in ("arithmetic_noise", "noise_table"):
+            for tag in ("arithmetic_noise", "noise_table", "noise_table_cost_ordered"):
                 if tag in heavy:
                     heavy[tag]["valu_roofline_frac"] = round(heavy["ops_per_ray"] * rays / (heavy[tag]["ms_per_step"] * 1e-3) / 1e12
                                                              / VALU_PEAK_TOPS, 4)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 2
+#define RRT_ABI_VERSION 3      /* 3: rrt_params.tile_order, rrt_tile_order_* */
 
 typedef enum {
     RRT_OK = 0,
@@ -100,6 +100,12 @@ typedef struct rrt_params {
                                 share a few lattice cells (4K / 8K frames: most of them) -- same bits, about
                                 half the media cost.  Ignored when `time` lies outside
                                 the table's [0, t_max].                                                   */
+    int32_t tile_order;      /* 0 (default): wave tiles are dispatched in the static order (row blocks from the middle
+                                of the frame outwards).  An rrt_tile_order id: the launch records what every wave tile
+                                cost and the next launch of the same geometry through that object dispatches
+                                longest-first -- same pixels; removes the drain of views whose long rays are not in the
+                                middle (a 4K frame from inside the disk: 53 -> 46 ms), nothing to gain on the
+                                reference's default view.  Single-kernel path only.                           */
 } rrt_params;
 
 #define RRT_PATH_AUTO 0
@@ -153,6 +159,20 @@ int rrt_workspace_destroy(int id);
 int rrt_workspace_stats(int id, unsigned* rows_used, unsigned* overflow_waves);
 /* inspection: copy `bytes` of the pool starting at `offset` to host memory (synchronous) */
 int rrt_workspace_read(int id, size_t offset, size_t bytes, void* host_dst);
+
+/* ---- cost-ordered dispatch (rrt_params.tile_order; no counterpart in the reference, whose launch is one fixed grid,
+ *      src/raymarcher.cu:176-180).  The object holds, per 8x8-pixel wave tile, the shader clocks the last launch
+ *      through it took, and the permutation (sorted on the device right after that launch, on its stream) the next
+ *      launch with the same width / height / row map reads.  A launch with another geometry renders in the static order
+ *      and starts over.  Launches through one object are serialised on the device, also across streams: give every frame
+ *      that should overlap another its own object (the headless drivers: one per slot).  Frames of an animation change
+ *      little from one to the next, which is what makes the previous frame's costs a good order for this one. ---- */
+int rrt_tile_order_create(int* out_id);
+int rrt_tile_order_destroy(int id);
+/* counters; with perm_host / cost_host (either may be NULL; `capacity` elements each) also, after waiting for the
+ * object's last launch, the order the next matching launch will use and the costs the last one recorded */
+int rrt_tile_order_info(int id, unsigned long long* launches, unsigned long long* ordered_launches, unsigned* n_tiles,
+                        unsigned* perm_host, unsigned* cost_host, unsigned capacity);
 
 /* ---- lattice-hash tables for the volumetric noise (rrt_params.noise_table): hash31 (math_utils.h:91-96) of
  *      every lattice point the low-octave noise3D calls of getAccretionDensity / getDustCloudDensity

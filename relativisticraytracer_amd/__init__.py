@@ -25,7 +25,7 @@ __all__ = ["CameraState", "CameraEffects", "RenderParams", "SkyTexture", "Worksp
            "set_launch_defaults", "get_launch_defaults",
            "launch_raymarch_rows", "launch_raymarch_tiles", "assemble_tiles", "assemble_all_tiles",
            "tile_shard_rows",
-           "launch_raymarch_debug", "RRTError", "device_count", "abi_version"]
+           "launch_raymarch_debug", "RRTError", "device_count", "abi_version", "TileOrder"]
 
 
 def _ptr(x):
@@ -163,6 +163,43 @@ class Workspace:
     def destroy(self):
         if getattr(self, "id", 0):
             _lib.load().rrt_workspace_destroy(self.id)
+            self.id = 0
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class TileOrder:
+    """Cost-ordered dispatch (RenderParams.tile_order = order.id): a launch through the object records what every 8x8-pixel
+    wave tile cost, and the next launch with the same geometry dispatches longest-first.  Same pixels; removes the drain
+    of views whose long rays are not in the middle of the frame.  Launches through one object are serialised on the
+    device: frames that should overlap need one each."""
+
+    def __init__(self):
+        i = C.c_int(0)
+        _lib.check(_lib.load().rrt_tile_order_create(C.byref(i)), "rrt_tile_order_create")
+        self.id = i.value
+
+    def info(self, arrays=False):
+        """{"launches", "ordered_launches", "n_tiles"}; with arrays=True also "perm" (the order the next matching launch
+        will use) and "cost" (shader clocks / 16 per wave tile of the last launch) as numpy arrays (synchronises)."""
+        import numpy as np
+        lib = _lib.load()
+        a, b, n = C.c_ulonglong(0), C.c_ulonglong(0), C.c_uint(0)
+        _lib.check(lib.rrt_tile_order_info(self.id, C.byref(a), C.byref(b), C.byref(n), None, None, 0), "rrt_tile_order_info")
+        out = {"launches": a.value, "ordered_launches": b.value, "n_tiles": n.value}
+        if arrays and n.value:
+            perm = np.empty(n.value, np.uint32); cost = np.empty(n.value, np.uint32)
+            _lib.check(lib.rrt_tile_order_info(self.id, None, None, None, perm.ctypes.data, cost.ctypes.data, n.value), "rrt_tile_order_info")
+            out["perm"], out["cost"] = perm, cost
+        return out
+
+    def destroy(self):
+        if getattr(self, "id", 0):
+            _lib.load().rrt_tile_order_destroy(self.id)
             self.id = 0
 
     def __del__(self):

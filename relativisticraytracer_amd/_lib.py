@@ -39,7 +39,7 @@ class rrt_effects(C.Structure):
 class rrt_params(C.Structure):
     _fields_ = [("spin", C.c_float), ("max_steps", C.c_int32), ("volumetrics", C.c_int32),
                 ("sky_frac_bits", C.c_int32), ("arith_mode", C.c_int32), ("workspace", C.c_int32),
-                ("path_policy", C.c_int32), ("noise_table", C.c_int32)]
+                ("path_policy", C.c_int32), ("noise_table", C.c_int32), ("tile_order", C.c_int32)]
 
 
 class rrt_debug_outputs(C.Structure):
@@ -63,6 +63,9 @@ SYMBOLS = [
     ("rrt_sky_destroy", _i, [_ull]),
     ("rrt_workspace_create", _i, [C.c_size_t, C.POINTER(_i)]),
     ("rrt_workspace_destroy", _i, [_i]),
+    ("rrt_tile_order_create", _i, [C.POINTER(_i)]),
+    ("rrt_tile_order_destroy", _i, [_i]),
+    ("rrt_tile_order_info", _i, [_i, C.POINTER(_ull), C.POINTER(_ull), C.POINTER(C.c_uint), _vp, _vp, C.c_uint]),
     ("rrt_noise_table_create", _i, [_f, C.POINTER(_i)]),
     ("rrt_noise_table_destroy", _i, [_i]),
     ("rrt_noise_table_info", _i, [_i, C.POINTER(_f), C.POINTER(C.c_size_t), C.POINTER(_i * 12)]),

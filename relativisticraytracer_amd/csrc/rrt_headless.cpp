@@ -101,6 +101,7 @@ struct Device {                // everything one GPU owns
     int noise_table = 0;
     float table_t0 = 0.0f, table_t1 = -1.0f;      // window of noise_table (empty: none yet)
     int pool[kMaxSlots] = {};
+    int order[kMaxSlots] = {};                    // rrt_tile_order per slot (0: static dispatch order)
     hipStream_t stream[kMaxSlots] = {};
     void* tiles[kMaxSlots] = {};                  // this device's shard of a frame
     int shard_rows = 0;
@@ -112,6 +113,7 @@ struct Device {                // everything one GPU owns
 int main(int argc, char** argv) {
     int w = 1000, h = 700, frames = 24, fps = 24, path = -1, sky_seed = 1, all_fx = 0, fast = 0;   // config.h:7-9
     int gpus = 1, tile_rows = 16, workspace_gib = 2, use_table = 1, force_collective = 0;
+    int tile_order = -1;           // cost-ordered dispatch: -1 auto (on when frames are rendered one at a time), 0 off, 1 on
     int kSlots = 3;                // frames in flight: frame k renders on stream k mod kSlots while its predecessors are
                                    // gathered / assembled / copied out (a rank's share of a frame is only a few rounds of
                                    // wavefronts; 3 measured best at 8 shards of a 4K frame: profiles/r02_frames_in_flight.txt)
@@ -128,6 +130,7 @@ int main(int argc, char** argv) {
         else if (a == "--spin" && i + 1 < argc) spin = (float)atof(argv[++i]);
         else if (a == "--noise-table-gib" && i + 1 < argc) table_gib = atof(argv[++i]);
         else if (a == "--no-noise-table") use_table = 0;
+        else if (a == "--tile-order") tile_order = 1; else if (a == "--no-tile-order") tile_order = 0;
         else if (a == "--force-collective") force_collective = 1;     // run the RCCL exchange even with one GPU (self-check)
         else if (a == "--out" && i + 1 < argc) out_path = argv[++i];
         else if (a == "--all-effects") all_fx = 1; else if (a == "--fast") fast = 1;
@@ -174,6 +177,10 @@ int main(int argc, char** argv) {
             HIPCHK(hipMalloc(&D.tiles[s], shard_stride));
             if (workspace_gib > 0 && (rc = rrt_workspace_create(((size_t)workspace_gib << 30) / kSlots, &D.pool[s])) != RRT_OK)
                 return fail("workspace", rc);
+            // every frame's wave tiles dispatched longest-first by what the slot's previous frame measured: worth it when the
+            // frames do not overlap (their drains are exposed), a wash when they do
+            if ((tile_order == 1 || (tile_order < 0 && kSlots == 1)) && (rc = rrt_tile_order_create(&D.order[s])) != RRT_OK)
+                return fail("tile order", rc);
         }
     }
     trace("per-device resources ready");
@@ -258,7 +265,7 @@ int main(int argc, char** argv) {
             HIPCHK(hipSetDevice(d));
             rrt_params prm; rrt_params_default(&prm);
             prm.spin = spin; prm.arith_mode = fast ? RRT_ARITH_FAST : RRT_ARITH_STRICT;
-            prm.workspace = D.pool[slot]; prm.noise_table = D.noise_table;
+            prm.workspace = D.pool[slot]; prm.noise_table = D.noise_table; prm.tile_order = D.order[slot];
             void* dst = collective ? D.tiles[slot] : frame[slot];
             if (collective) rc = rrt_launch_raymarch_tiles(dst, w, h, tile_rows, d, gpus, sim_t, &cam, D.sky, &fx, &prm, D.stream[slot]);
             else rc = rrt_launch_raymarch(dst, w, h, sim_t, &cam, D.sky, &fx, &prm, D.stream[slot]);
@@ -294,9 +301,10 @@ int main(int argc, char** argv) {
     if (f) fclose(f);
     printf("{\"frames\": %d, \"width\": %d, \"height\": %d, \"n_gpus\": %d, \"seconds\": %.4f, \"fps\": %.3f, \"Mrays_per_s\": %.3f, "
            "\"path\": \"%s\", \"spin\": %g, \"arith_mode\": \"%s\", \"noise_tables\": {\"builds\": %d, \"table_frames\": %d, "
-           "\"arith_frames\": %d, \"coarsest_coverage\": %d, \"peak_bytes\": %zu, \"budget_bytes\": %zu}, \"collective\": \"%s\"}\n",
+           "\"arith_frames\": %d, \"coarsest_coverage\": %d, \"peak_bytes\": %zu, \"budget_bytes\": %zu}, \"tile_order\": %s, \"collective\": \"%s\"}\n",
            frames, w, h, gpus, dt, frames / dt, (double)frames * w * h / dt / 1e6, path_name, spin, fast ? "fast" : "strict",
-           table_builds, table_frames, arith_frames, coarsest, table_peak, table_budget, collective ? "rccl grouped send/recv gather" : "none");
+           table_builds, table_frames, arith_frames, coarsest, table_peak, table_budget, dev[0].order[0] ? "true" : "false",
+           collective ? "rccl grouped send/recv gather" : "none");
 
     for (int d = 0; d < gpus; ++d) {
         Device& D = dev[d];
@@ -304,6 +312,7 @@ int main(int argc, char** argv) {
         if (D.comm) ncclCommDestroy(D.comm);
         for (int s = 0; s < kSlots; ++s) {
             if (D.pool[s]) rrt_workspace_destroy(D.pool[s]);
+            if (D.order[s]) rrt_tile_order_destroy(D.order[s]);
             (void)hipFree(D.tiles[s]);
             (void)hipStreamDestroy(D.stream[s]);
         }

@@ -17,6 +17,7 @@
  *   C ABI of include/rrt.h, sky and workspace registries, camera basis / path playback
  */
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>        /* DeviceRadixSort for rrt_tile_order */
 
 #include <atomic>
 #include <cmath>
@@ -310,7 +311,44 @@ struct FrameArgs {
     unsigned block_capacity;
     /* lattice-hash tables (rrt_noise_table); only read by the kernels instantiated with MEDIA == 2 */
     NoiseLut lut_acc, lut_dust;
+    /* cost-ordered dispatch of the single-kernel path (rrt_tile_order): dispatch slot -> wave tile, and where a wave
+     * leaves the clocks it took; both NULL: the static centre-out order */
+    const unsigned* tile_perm;
+    unsigned* tile_cost;
+    int tile_order_id;      /* host side only: rrt_params.tile_order */
 };
+
+/* ------------------------------------------------------------------ cost-ordered dispatch (rrt_tile_order)
+ * Workgroups are dispatched in blockIdx order and a wave tile's cost is only known once it has been rendered, so the
+ * static order (row blocks from the middle outwards) is right for the reference's default view and wrong wherever the
+ * longest rays are somewhere else: from inside the disk a 4K frame spends 8 % of its time draining.
+ * An rrt_tile_order object remembers, per wave tile, the clocks the previous launch through it took, and dispatches the
+ * next launch of the same geometry longest-first (one radix sort of n_tiles keys after the frame, ~20 us).  Any order
+ * renders the same pixels.  All launches through one object are serialised on the device (an event chains them across
+ * streams): frames that should overlap need an object each. */
+struct TileOrderObject {
+    int device;
+    unsigned* d_cost;        /* clocks >> 4 of each wave tile, written by the render kernel */
+    unsigned* d_sorted;      /* the sort's key output (unused) */
+    unsigned* d_iota;        /* 0 .. n_cap-1 */
+    unsigned* d_perm[2];     /* dispatch slot -> wave tile; [cur] is the one the next matching launch reads */
+    void* d_temp; size_t temp_bytes;
+    size_t n_cap;
+    int cur;
+    bool have;               /* d_perm[cur] holds an order for the geometry below */
+    unsigned grid_x, grid_y;
+    int width, height; RowMap rows;
+    hipEvent_t chained;      /* after the last sort */
+    unsigned long long launches, ordered;
+};
+std::mutex g_to_mu;
+std::unordered_map<int, TileOrderObject> g_to;
+int g_to_next = 1;
+
+__global__ __launch_bounds__(256) void fill_iota(unsigned* v, unsigned n) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) v[i] = i;
+}
 
 /* image row of local row `lr`, and the local output row it is stored at */
 __device__ __forceinline__ bool map_row(const RowMap& m, int height, int lr, int& y, int& out_row) {
@@ -611,10 +649,24 @@ __device__ __forceinline__ int tile_column() {
     const unsigned id = blockIdx.y * gridDim.x + bx;          /* dispatch order: id % 8 labels the XCD */
     return base + (int)(id & 7u) * L + (((bx - base) >> 3) % L);
 }
+/* A wave tile's cost is its lifetime in shader clocks / 16, clamped to 22 bits (a wave that lives 30 ms); the order only
+ * needs bits 6..21 of it (0.5 us steps), which is what the radix sort looks at: two 8-bit passes. */
+constexpr unsigned kTileCostMax = (1u << 22) - 1u;
+constexpr int kTileCostSortLo = 6, kTileCostSortHi = 22;
+
+/* the wave tile (row_block * gridDim.x + column) this workgroup renders: the static order above, or the launch's
+ * cost-ordered permutation */
+__device__ __forceinline__ unsigned wave_tile(const FrameArgs& a) {
+    if (a.tile_perm) return a.tile_perm[blockIdx.y * gridDim.x + blockIdx.x];
+    return (unsigned)(row_block() * (int)gridDim.x + tile_column());
+}
 __device__ __forceinline__ bool lane_pixel(const FrameArgs& a, int& x, int& y, int& out_row) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    x = tile_column() * kWGPixX + (wave & 1) * kTileW + (lane & (kTileW - 1));
-    const int lr = row_block() * kWGPixY + (wave >> 1) * kTileH + lane / kTileW;
+    int col, rb;
+    if (a.tile_perm) { const unsigned t = wave_tile(a); rb = (int)(t / gridDim.x); col = (int)(t - (unsigned)rb * gridDim.x); }
+    else { col = tile_column(); rb = row_block(); }
+    x = col * kWGPixX + (wave & 1) * kTileW + (lane & (kTileW - 1));
+    const int lr = rb * kWGPixY + (wave >> 1) * kTileH + lane / kTileW;
     return x < a.width && map_row(a.rows, a.height, lr, y, out_row);
 }
 /* max over the live lanes of a wave; lanes that are not executing contribute 0 */
@@ -647,6 +699,7 @@ void raymarch_pixels(const FrameArgs a) {
     __shared__ volatile int occ_pad[RRT_OCC_PROBE_LDS / 4];
     if (MEDIA == 0) occ_pad[threadIdx.x] = 0;
 #endif
+    const unsigned long long t_start = a.tile_cost ? __builtin_readcyclecounter() : 0ull;
     int x, y, out_row;
     if (!lane_pixel(a, x, y, out_row)) return;
     float uvx, uvy;
@@ -657,6 +710,10 @@ void raymarch_pixels(const FrameArgs a) {
     int i = 0;
     march_inline<SPIN, MEDIA, FAST>(a, p, vel, acc, hit, i, DEBUG ? a.dbg.d_lut_oob : nullptr);
     shade_and_store<DEBUG>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, i);
+    if (a.tile_cost) {          /* what this wave cost, for the next launch's order (every lane stores the same word) */
+        const unsigned long long dt = (__builtin_readcyclecounter() - t_start) >> 4;
+        a.tile_cost[wave_tile(a)] = dt > kTileCostMax ? kTileCostMax : (unsigned)dt;
+    }
 }
 
 /* ---- three-pass path, pass 1: geodesics only; sample points of in-medium steps go to the pool ---- */
@@ -1216,7 +1273,7 @@ int check_common(const void* out, int width, int height, const rrt_camera* cam, 
         if (prm->arith_mode != RRT_ARITH_STRICT && prm->arith_mode != RRT_ARITH_FAST) return RRT_ERR_INVALID_ARGUMENT;
         if (prm->workspace < 0) return RRT_ERR_INVALID_ARGUMENT;
         if (prm->path_policy < RRT_PATH_AUTO || prm->path_policy > RRT_PATH_THREE_PASS) return RRT_ERR_INVALID_ARGUMENT;
-        if (prm->noise_table < 0) return RRT_ERR_INVALID_ARGUMENT;
+        if (prm->noise_table < 0 || prm->tile_order < 0) return RRT_ERR_INVALID_ARGUMENT;
     }
     return RRT_OK;
 }
@@ -1240,6 +1297,7 @@ int fill_args(FrameArgs& a, int& media, bool& fast, int& workspace, int& policy,
     a.drag_c = (2.0f * prm.spin) * 2.0f;            /* 2.0f * SPIN_A * EVENT_HORIZON, geodesics.h:41 */
     a.max_steps = prm.max_steps;
     memset(&a.dbg, 0, sizeof(a.dbg));
+    a.tile_perm = nullptr; a.tile_cost = nullptr; a.tile_order_id = prm.tile_order;
     media = prm.volumetrics != 0 ? 1 : 0;
     memset(&a.lut_acc, 0, sizeof(a.lut_acc)); memset(&a.lut_dust, 0, sizeof(a.lut_dust));
     if (prm.noise_table != 0) {
@@ -1322,6 +1380,32 @@ int launch_deferred(FrameArgs a, bool fast, bool lut, const WorkspaceObject& ws,
 constexpr long long kThreePassMaxRays = 1500000;
 
 /* media: 0 = off, 1 = on, 2 = on with the lattice-hash tables (a.lut_*) */
+/* room for n tiles in a tile-order object (grows only; growing forgets the order) */
+int tile_order_reserve(TileOrderObject& o, size_t n) {
+    if (n <= o.n_cap) return RRT_OK;
+    if (n > ((size_t)1 << 30)) return RRT_ERR_INVALID_ARGUMENT;
+    RRT_HIP(hipDeviceSynchronize());                 /* launches through the object may still read the old buffers */
+    unsigned** bufs[] = {&o.d_cost, &o.d_sorted, &o.d_iota, &o.d_perm[0], &o.d_perm[1]};
+    for (unsigned** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+    if (o.d_temp) (void)hipFree(o.d_temp);
+    o.d_temp = nullptr; o.n_cap = 0; o.have = false;
+    const size_t cap = n + n / 8;
+    for (unsigned** b : bufs) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(b), cap * sizeof(unsigned));
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc(tile order)");
+    }
+    size_t tb = 0;
+    RRT_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, o.d_cost, o.d_sorted, o.d_iota, o.d_perm[0], (int)cap, kTileCostSortLo, kTileCostSortHi, nullptr));
+    hipError_t e = hipMalloc(&o.d_temp, tb > 0 ? tb : 16);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(tile order sort)");
+    o.temp_bytes = tb;
+    fill_iota<<<dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, nullptr>>>(o.d_iota, (unsigned)cap);
+    RRT_HIP(hipGetLastError());
+    RRT_HIP(hipDeviceSynchronize());
+    o.n_cap = cap;
+    return RRT_OK;
+}
+
 int launch(const FrameArgs& a, int media, bool debug, bool fast, int workspace, int policy, hipStream_t st) {
     dim3 block(kWGThreads);
     if (a.rows.n_local_rows == 0) return RRT_OK;
@@ -1343,7 +1427,28 @@ int launch(const FrameArgs& a, int media, bool debug, bool fast, int workspace, 
     }
     const bool spin = a.spin != 0.0f;
     dim3 grid((a.width + kWGPixX - 1) / kWGPixX, (a.rows.n_local_rows + kWGPixY - 1) / kWGPixY);
-#define RRT_LAUNCH4(S, M, D, F) hipLaunchKernelGGL((raymarch_pixels<S, M, D, F>), grid, block, 0, st, a)
+    FrameArgs b = a;
+    /* cost-ordered dispatch: read the order the previous launch through the object left (same geometry only), record
+     * this launch's costs, sort them into the other buffer for the next one */
+    TileOrderObject* order = nullptr;
+    std::unique_lock<std::mutex> order_lock;
+    const size_t n_tiles = (size_t)grid.x * grid.y;
+    if (a.tile_order_id != 0 && !debug && kWGWaves == 1) {
+        order_lock = std::unique_lock<std::mutex>(g_to_mu);
+        auto it = g_to.find(a.tile_order_id);
+        if (it == g_to.end() || !on_current_device(it->second.device)) return RRT_ERR_BAD_HANDLE;
+        order = &it->second;
+        int rc = tile_order_reserve(*order, n_tiles);
+        if (rc != RRT_OK) return rc;
+        if (order->launches > 0) RRT_HIP(hipStreamWaitEvent(st, order->chained, 0));
+        const bool same = order->have && order->grid_x == grid.x && order->grid_y == grid.y && order->width == a.width &&
+                          order->height == a.height && memcmp(&order->rows, &a.rows, sizeof(RowMap)) == 0;
+        b.tile_perm = same ? order->d_perm[order->cur] : nullptr;
+        b.tile_cost = order->d_cost;
+        RRT_HIP(hipMemsetAsync(order->d_cost, 0, n_tiles * sizeof(unsigned), st));
+        if (same) ++order->ordered;
+    }
+#define RRT_LAUNCH4(S, M, D, F) hipLaunchKernelGGL((raymarch_pixels<S, M, D, F>), grid, block, 0, st, b)
 #define RRT_LAUNCH3(S, M, D) do { if (fast) RRT_LAUNCH4(S, M, D, true); else RRT_LAUNCH4(S, M, D, false); } while (0)
 #define RRT_LAUNCH2(S, M) do { if (debug) RRT_LAUNCH3(S, M, true); else RRT_LAUNCH3(S, M, false); } while (0)
 #define RRT_LAUNCH1(S) do { if (media == 2) RRT_LAUNCH2(S, 2); else if (media == 1) RRT_LAUNCH2(S, 1); else RRT_LAUNCH2(S, 0); } while (0)
@@ -1353,6 +1458,15 @@ int launch(const FrameArgs& a, int media, bool debug, bool fast, int workspace, 
 #undef RRT_LAUNCH3
 #undef RRT_LAUNCH4
     RRT_HIP(hipGetLastError());
+    if (order) {
+        const int next = order->cur ^ 1;
+        size_t tb = order->temp_bytes;
+        RRT_HIP(hipcub::DeviceRadixSort::SortPairsDescending(order->d_temp, tb, order->d_cost, order->d_sorted, order->d_iota,
+                                                             order->d_perm[next], (int)n_tiles, kTileCostSortLo, kTileCostSortHi, st));
+        RRT_HIP(hipEventRecord(order->chained, st));
+        order->cur = next; order->have = true; ++order->launches;
+        order->grid_x = grid.x; order->grid_y = grid.y; order->width = a.width; order->height = a.height; order->rows = a.rows;
+    }
     return RRT_OK;
 }
 
@@ -1385,7 +1499,7 @@ const char* rrt_status_string(int s) {
         case RRT_ERR_INVALID_ARGUMENT: return "invalid argument";
         case RRT_ERR_NO_DEVICE: return "no HIP device";
         case RRT_ERR_HIP: return "HIP runtime error";
-        case RRT_ERR_BAD_HANDLE: return "bad handle (sky, workspace or noise table)";
+        case RRT_ERR_BAD_HANDLE: return "bad handle (sky, workspace, noise table or tile order)";
         case RRT_ERR_OUT_OF_MEMORY: return "out of memory";
         default: return "unknown status";
     }
@@ -1473,6 +1587,58 @@ int rrt_workspace_create(size_t bytes, int* out) {
     return RRT_OK;
 }
 
+int rrt_tile_order_create(int* out) {
+    if (!out) return RRT_ERR_INVALID_ARGUMENT;
+    TileOrderObject o;
+    memset(&o, 0, sizeof(o));
+    o.device = current_device();
+    RRT_HIP(hipEventCreateWithFlags(&o.chained, hipEventDisableTiming));
+    std::lock_guard<std::mutex> lk(g_to_mu);
+    *out = g_to_next++;
+    g_to.emplace(*out, o);
+    return RRT_OK;
+}
+
+int rrt_tile_order_destroy(int id) {
+    TileOrderObject o;
+    {
+        std::lock_guard<std::mutex> lk(g_to_mu);
+        auto it = g_to.find(id);
+        if (it == g_to.end()) return RRT_ERR_BAD_HANDLE;
+        if (!on_current_device(it->second.device)) return RRT_ERR_BAD_HANDLE;
+        o = it->second;
+        g_to.erase(it);
+    }
+    if (o.launches > 0) (void)hipEventSynchronize(o.chained);      /* its last launch and sort have finished */
+    unsigned* bufs[] = {o.d_cost, o.d_sorted, o.d_iota, o.d_perm[0], o.d_perm[1]};
+    for (unsigned* b : bufs) if (b) (void)hipFree(b);
+    if (o.d_temp) (void)hipFree(o.d_temp);
+    (void)hipEventDestroy(o.chained);
+    return RRT_OK;
+}
+
+/* counters of an object, and (optionally, after waiting for its last launch) the order the NEXT matching launch will
+ * use plus the costs the last one recorded: perm_host / cost_host may be NULL, capacity counts elements */
+int rrt_tile_order_info(int id, unsigned long long* launches, unsigned long long* ordered_launches, unsigned* n_tiles,
+                        unsigned* perm_host, unsigned* cost_host, unsigned capacity) {
+    std::lock_guard<std::mutex> lk(g_to_mu);
+    auto it = g_to.find(id);
+    if (it == g_to.end()) return RRT_ERR_BAD_HANDLE;
+    const TileOrderObject& o = it->second;
+    if (!on_current_device(o.device)) return RRT_ERR_BAD_HANDLE;
+    const unsigned n = o.have ? o.grid_x * o.grid_y : 0u;
+    if (launches) *launches = o.launches;
+    if (ordered_launches) *ordered_launches = o.ordered;
+    if (n_tiles) *n_tiles = n;
+    if ((perm_host || cost_host) && n > 0) {
+        if (capacity < n) return RRT_ERR_INVALID_ARGUMENT;
+        RRT_HIP(hipEventSynchronize(o.chained));
+        if (perm_host) RRT_HIP(hipMemcpy(perm_host, o.d_perm[o.cur], n * sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (cost_host) RRT_HIP(hipMemcpy(cost_host, o.d_cost, n * sizeof(unsigned), hipMemcpyDeviceToHost));
+    }
+    return RRT_OK;
+}
+
 /* Parameters of the reference-signature entry point launch_raymarch() (include/raymarcher.h), which has no
  * parameter for them: config.h defaults until the application says otherwise.  Nothing is allocated here --
  * a workspace or noise table named in the defaults is created (and destroyed) by the caller. */
@@ -1485,7 +1651,7 @@ int rrt_set_launch_defaults(const rrt_params* prm) {
     if (!prm) { g_defaults_set = false; return RRT_OK; }
     if (prm->max_steps < 0 || prm->sky_frac_bits < 0 || prm->sky_frac_bits > 16 || !(prm->spin == prm->spin) ||
         (prm->arith_mode != RRT_ARITH_STRICT && prm->arith_mode != RRT_ARITH_FAST) || prm->workspace < 0 ||
-        prm->path_policy < RRT_PATH_AUTO || prm->path_policy > RRT_PATH_THREE_PASS || prm->noise_table < 0)
+        prm->path_policy < RRT_PATH_AUTO || prm->path_policy > RRT_PATH_THREE_PASS || prm->noise_table < 0 || prm->tile_order < 0)
         return RRT_ERR_INVALID_ARGUMENT;
     g_defaults = *prm;
     g_defaults_set = true;

@@ -34,6 +34,10 @@ def main(argv=None):
                     help="several ranks: frames rendered / gathered / assembled concurrently per rank (>= 2)")
     ap.add_argument("--workspace-gib", type=int, default=8,
                     help="per-rank pool for the three-pass path, used by launches of <= 1.5 M rays (0 = single kernel only)")
+    ap.add_argument("--tile-order", choices=("auto", "on", "off"), default="auto",
+                    help="cost-ordered dispatch (rrt_tile_order): every frame's wave tiles go out longest-first by the costs the "
+                         "previous frame (of the same slot) measured.  auto: on when frames are rendered one at a time, off when "
+                         "several are in flight (their drains already overlap)")
     ap.add_argument("--no-noise-table", action="store_true",
                     help="hash every noise3D corner arithmetically (default: lattice-hash tables over a sliding window of the clock)")
     ap.add_argument("--noise-table-gib", type=float, default=2.0,
@@ -92,8 +96,10 @@ def main(argv=None):
     t_end, _ = camera_paths.recording_clock(max(args.frames, 1), args.fps)
     nwin = rrt.NoiseWindows(float(t_end) + 1.0, int(args.noise_table_gib * (1 << 30)), sync=torch.cuda.synchronize,
                             enabled=not args.no_noise_table and not args.no_volumetrics)
+    use_order = args.tile_order == "on" or (args.tile_order == "auto" and n_slots == 1)
+    orders = [rrt.TileOrder() for _ in range(n_slots)] if use_order else []
     prms = [rrt.RenderParams(spin=args.spin, volumetrics=0 if args.no_volumetrics else 1,
-                             noise_table=0,
+                             noise_table=0, tile_order=orders[j].id if orders else 0,
                              arith_mode=1 if args.fast else 0, workspace=pools[j].id if pools else 0,
                              path_policy=int(os.environ.get("RRT_PATH_POLICY", "0"))) for j in range(n_slots)]
     path = camera_paths.CameraPath(args.path) if args.path >= 0 else None
@@ -146,10 +152,13 @@ def main(argv=None):
                           "fps": round(args.frames / dt, 3), "Mrays_per_s": round(args.frames * w * h / dt / 1e6, 3),
                           "path": path.name if path else None, "spin": args.spin,
                           "arith_mode": "fast" if args.fast else "strict", "sink": args.out,
-                          "noise_tables": nwin.summary()}), flush=True)
+                          "noise_tables": nwin.summary(),
+                          "tile_order": orders[0].info() if orders else None}), flush=True)
     if world > 1:
         dist.destroy_process_group()
     nwin.close()
+    for o in orders:
+        o.destroy()
     tex.destroy()
 
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.rrt_abi_version() == 2
+    assert lib.rrt_abi_version() == 3
 
 
 def test_library_exports_launch_raymarch_as_a_cpp_symbol():
@@ -174,7 +174,7 @@ def test_struct_layouts_match_the_reference_structs():
     assert [offs[k] for k in ("use_bloom", "bloom_threshold", "bloom_intensity", "use_vignette",
                               "vignette_intensity", "use_chromatic_aberration", "ca_amount",
                               "use_lens_distortion", "distortion_amount")] == [0, 4, 8, 12, 16, 20, 24, 28, 32]
-    assert C.sizeof(_lib.rrt_params) == 32
+    assert C.sizeof(_lib.rrt_params) == 36          # ABI 3: + tile_order
 
 
 def test_defaults_are_the_reference_defaults():
@@ -216,3 +216,19 @@ def test_camera_from_angles_matches_reference_formula():
     assert np.allclose(a[3], np.cross(a[1], a[2]), atol=1e-7)
     for v in a[1:]:
         assert abs(np.linalg.norm(v) - 1) < 1e-6
+
+
+def test_tile_order_argument_checks_need_no_gpu():
+    """rrt_params.tile_order (ABI 3): default 0, negative ids refused, unknown ids are bad handles -- all before anything
+    touches a device."""
+    import ctypes as C
+    from relativisticraytracer_amd import _lib
+    lib = _lib.load()
+    prm = _lib.rrt_params()
+    assert lib.rrt_params_default(C.byref(prm)) == 0
+    assert prm.tile_order == 0 and C.sizeof(_lib.rrt_params) == 36
+    prm.tile_order = -1
+    assert lib.rrt_set_launch_defaults(C.byref(prm)) == 1          # RRT_ERR_INVALID_ARGUMENT
+    assert lib.rrt_tile_order_create(None) == 1
+    assert lib.rrt_tile_order_destroy(12345) == 4                  # RRT_ERR_BAD_HANDLE
+    assert lib.rrt_tile_order_info(12345, None, None, None, None, None, 0) == 4

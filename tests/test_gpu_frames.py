@@ -785,7 +785,7 @@ def test_handles_are_tied_to_their_device(ctx):
     w, h = 64, 36
     cam = rrt.CameraState.default(); fx = rrt.CameraEffects()
     out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
-    nt = rrt.NoiseTable(2.0); ws = rrt.Workspace(64 << 20)
+    nt = rrt.NoiseTable(2.0); ws = rrt.Workspace(64 << 20); order = rrt.TileOrder()
     real = torch.cuda.current_device()
     try:
         assert nt.info()["device"] == real
@@ -804,6 +804,9 @@ def test_handles_are_tied_to_their_device(ctx):
         for prm in (rrt.RenderParams(spin=0.9, noise_table=nt.id), rrt.RenderParams(spin=0.9, workspace=ws.id, path_policy=2)):
             assert lib.rrt_launch_raymarch(C.c_void_p(out.data_ptr()), w, h, 1.0, C.byref(a), sky2, C.byref(fx), C.byref(prm), None) == 4
         assert lib.rrt_workspace_stats(ws.id, None, None) == 4
+        assert lib.rrt_tile_order_info(order.id, None, None, None, None, None, 0) == 4
+        prm = rrt.RenderParams(spin=0.9, tile_order=order.id)
+        assert lib.rrt_launch_raymarch(C.c_void_p(out.data_ptr()), w, h, 1.0, C.byref(a), sky2, C.byref(fx), C.byref(prm), None) == 4
         lib.rrt_sky_destroy(sky2)
         lib.rrt_debug_fake_device(-1)
         out.zero_()
@@ -812,7 +815,76 @@ def test_handles_are_tied_to_their_device(ctx):
         assert torch.equal(out, ref)
     finally:
         lib.rrt_debug_fake_device(-1)
-        nt.destroy(); ws.destroy()
+        nt.destroy(); ws.destroy(); order.destroy()
+
+
+def test_cost_ordered_dispatch_renders_the_same_frames(ctx):
+    """rrt_tile_order (round 3): launches through the object record per-wave-tile costs and the next launch of the same
+    geometry dispatches longest-first.  Any order renders the same pixels: full frames, tile shards, fast mode, a
+    geometry change in between, two streams sharing one object; the order handed out is a permutation sorted by cost."""
+    import torch
+    g, rrt, tex = ctx
+    fx = rrt.CameraEffects(useChromaticAberration=True)
+    nt = rrt.NoiseTable(16.0)
+    views = [(rrt.CameraState.from_angles((4.2, 0.6, 4.2), -90.0, -5.7), 14.0), (rrt.CameraState.default(), 1.0)]
+    order = rrt.TileOrder()
+    try:
+        w, h = 640, 360
+        n_tiles = ((w + 7) // 8) * ((h + 7) // 8)
+        ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda"); out = torch.zeros_like(ref)
+        launches = ordered = 0
+        for cam, t in views:
+            for mode in (0, 1):
+                plain = rrt.RenderParams(spin=0.9, noise_table=nt.id, arith_mode=mode)
+                withorder = rrt.RenderParams(spin=0.9, noise_table=nt.id, arith_mode=mode, tile_order=order.id)
+                rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, plain)
+                for k in range(3):
+                    out.zero_()
+                    rrt.launch_raymarch(out, w, h, t, cam, tex, fx, withorder)
+                    torch.cuda.synchronize()
+                    assert torch.equal(out, ref), (mode, k)
+                    launches += 1; ordered += 1 if launches > 1 else 0
+                info = order.info(arrays=True)
+                assert (info["launches"], info["ordered_launches"], info["n_tiles"]) == (launches, ordered, n_tiles)
+                perm, cost = info["perm"], info["cost"]
+                assert np.array_equal(np.sort(perm), np.arange(n_tiles, dtype=np.uint32))            # a permutation ...
+                assert np.all(np.diff((cost[perm] >> 6).astype(np.int64)) <= 0) and cost.max() > 0     # ... longest first (in 0.5 us steps)
+        # another geometry: rendered in the static order (nothing to go by), and the object starts over
+        w2, h2 = 333, 130
+        ref2 = torch.zeros(h2 * w2 * 4, dtype=torch.uint8, device="cuda"); out2 = torch.zeros_like(ref2)
+        cam, t = views[0]
+        rrt.launch_raymarch(ref2, w2, h2, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id))
+        for k in range(2):
+            rrt.launch_raymarch(out2, w2, h2, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id, tile_order=order.id))
+            torch.cuda.synchronize()
+            assert torch.equal(out2, ref2)
+        info = order.info()
+        assert info["launches"] == launches + 2 and info["ordered_launches"] == ordered + 1
+        assert info["n_tiles"] == ((w2 + 7) // 8) * ((h2 + 7) // 8)
+        # tile shards (their own row map), and two streams sharing the object: the library chains them
+        rows = rrt.tile_shard_rows(h, 16, 1, 3)
+        sref = torch.zeros(rows * w * 4, dtype=torch.uint8, device="cuda"); sout = [torch.zeros_like(sref) for _ in range(2)]
+        rrt.launch_raymarch_tiles(sref, w, h, 16, 1, 3, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id))
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        torch.cuda.synchronize()
+        for k in range(6):
+            with torch.cuda.stream(streams[k % 2]):
+                rrt.launch_raymarch_tiles(sout[k % 2], w, h, 16, 1, 3, t, cam, tex, fx,
+                                          rrt.RenderParams(spin=0.9, noise_table=nt.id, tile_order=order.id), stream=streams[k % 2])
+        torch.cuda.synchronize()
+        assert torch.equal(sout[0], sref) and torch.equal(sout[1], sref)
+        # the three-pass path and debug launches ignore the object; a wrong id is a bad handle
+        ws = rrt.Workspace(256 << 20)
+        rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=ws.id, path_policy=2, tile_order=order.id))
+        rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id))
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        ws.destroy()
+        with pytest.raises(rrt.RRTError) as e:
+            rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, tile_order=order.id + 1000))
+        assert e.value.status == 4
+    finally:
+        order.destroy(); nt.destroy()
 
 
 def test_full_size_properties_4k(ctx):

@@ -101,7 +101,9 @@ def test_cpp_driver_rccl_gather_path_writes_the_same_frames(tmp_path):
     for extra in (["--force-collective"], ["--force-collective", "--tile-rows", "7", "--workspace-gib", "1"],
                   ["--force-collective", "--no-noise-table", "--workspace-gib", "0"], [],
                   ["--force-collective", "--frames-in-flight", "1"], ["--force-collective", "--frames-in-flight", "2"],
-                  ["--force-collective", "--frames-in-flight", "4"], ["--frames-in-flight", "4"]):
+                  ["--force-collective", "--frames-in-flight", "4"], ["--frames-in-flight", "4"],
+                  ["--tile-order", "--workspace-gib", "0"], ["--frames-in-flight", "1", "--workspace-gib", "0"],
+                  ["--frames-in-flight", "1", "--no-tile-order"]):
         out = tmp_path / "v.rgba"
         try:
             r = subprocess.run([exe] + base + extra + ["--out", str(out)], capture_output=True, text=True, timeout=240,
@@ -113,6 +115,9 @@ def test_cpp_driver_rccl_gather_path_writes_the_same_frames(tmp_path):
         meta = json.loads(r.stdout.strip().splitlines()[-1])
         assert meta["n_gpus"] == 1 and meta["frames"] == 5
         assert ("rccl" in meta["collective"]) == ("--force-collective" in extra)
+        # cost-ordered dispatch: on request, and by itself when frames are rendered one at a time
+        assert meta["tile_order"] == ("--tile-order" in extra or (extra[:2] == ["--frames-in-flight", "1"] and "--no-tile-order" not in extra)
+                                      or extra[:3] == ["--force-collective", "--frames-in-flight", "1"])
         assert open(out, "rb").read() == want, extra
     r = subprocess.run([exe] + base + ["--gpus", "99"], capture_output=True, text=True)
     assert r.returncode == 2 and "device(s) visible" in r.stderr
