@@ -957,12 +957,13 @@ def test_pipelined_sharder_over_one_rank_rccl(ctx):
 def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
     """Seeded random scenes (camera anywhere from inside the disk to far out, any orientation, spin of either
     sign, random time / effects / ragged size): the single kernel, the three-pass path with an ample and with
-    a starved pool, and interleaved tile shards must all give the oracle's bytes (portable math mode)."""
+    a starved pool, cost-ordered dispatch, and interleaved tile shards must all give the oracle's bytes (portable math mode)."""
     import torch
     g, rrt, tex = ctx
     rng = np.random.default_rng(int(os.environ.get("RRT_SWEEP_SEED", "20261004")))     # soaks vary the seed
     ample, starved = rrt.Workspace(512 << 20), rrt.Workspace(13 << 20)     # 13 MiB: the smallest useful pool
     nt = rrt.NoiseTable(30.0)
+    order = rrt.TileOrder()
     try:
         overflowed = 0
         for case in range(int(os.environ.get("RRT_SWEEP_CASES", "60"))):      # soak: RRT_SWEEP_CASES=600 (run on the round's final build)
@@ -1006,6 +1007,11 @@ def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
                 r = g.render_gpu(w, h, spin, 1, cam, t, tex, fx=fx, debug=False, noise_table=table)
                 assert np.array_equal(r["rgba8"], o["rgba8"]), (tag, "production kernel", table)
             want = torch.from_numpy(o["rgba8"].reshape(-1)).cuda()
+            for rep in range(2):            # cost-ordered dispatch: the first launch of a geometry in the static order, the second longest-first
+                out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+                rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=spin, noise_table=nt.id if case % 2 else 0, tile_order=order.id))
+                torch.cuda.synchronize()
+                assert torch.equal(out, want), (tag, "tile order", rep)
             for pool in (ample, starved):
                 out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
                 rrt.launch_raymarch(out, w, h, t, cam, tex, fx,
@@ -1026,5 +1032,7 @@ def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
             torch.cuda.synchronize()
             assert torch.equal(frame, want), (tag, n, R)
         assert overflowed > 0          # the starved pool did exercise the overflow route somewhere in the sweep
+        info = order.info()
+        assert info["ordered_launches"] >= info["launches"] // 2       # every scene's second launch (at least) was cost-ordered
     finally:
-        ample.destroy(); starved.destroy(); nt.destroy()
+        ample.destroy(); starved.destroy(); nt.destroy(); order.destroy()
