@@ -166,7 +166,9 @@ int rrt_workspace_read(int id, size_t offset, size_t bytes, void* host_dst);
  *      launch with the same width / height / row map reads.  A launch with another geometry renders in the static order
  *      and starts over.  Launches through one object are serialised on the device, also across streams: give every frame
  *      that should overlap another its own object (the headless drivers: one per slot).  Frames of an animation change
- *      little from one to the next, which is what makes the previous frame's costs a good order for this one. ---- */
+ *      little from one to the next, which is what makes the previous frame's costs a good order for this one.  The first
+ *      launch of a (larger) geometry allocates the object's buffers -- a synchronising call, not for stream capture; a
+ *      captured launch replays the order it was captured with (still a valid order: same pixels). ---- */
 int rrt_tile_order_create(int* out_id);
 int rrt_tile_order_destroy(int id);
 /* counters; with perm_host / cost_host (either may be NULL; `capacity` elements each) also, after waiting for the
