@@ -1,5 +1,5 @@
 """dev tool (GPU): 4K, a = 0.9 kernel times of the named views -- strict with arithmetic noise / without media / with
-the noise tables, and the fast mode the same way (the table of DESIGN.md section 4)."""
+the noise tables (static and cost-ordered dispatch), and the fast mode the same way (the table of DESIGN.md section 4)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -30,5 +30,10 @@ for name, pos, yaw, pitch, tt in VIEWS:
         r[mode] = (t(rrt.RenderParams(spin=0.9, arith_mode=mode), cam, tt),
                    t(rrt.RenderParams(spin=0.9, arith_mode=mode, volumetrics=0), cam, tt),
                    t(rrt.RenderParams(spin=0.9, arith_mode=mode, noise_table=nt.id), cam, tt))
-    print(f"{name:32s} strict {r[0][0]:7.2f} ms (no-vol {r[0][1]:6.2f}, table {r[0][2]:6.2f})   "
+    order = rrt.TileOrder()       # table + cost-ordered dispatch (rrt_tile_order; the sort behind every frame inside the time)
+    prm = rrt.RenderParams(spin=0.9, noise_table=nt.id, tile_order=order.id)
+    rrt.launch_raymarch(out, w, h, tt, cam, tex, fx, prm)
+    ordered = t(prm, cam, tt)
+    order.destroy()
+    print(f"{name:32s} strict {r[0][0]:7.2f} ms (no-vol {r[0][1]:6.2f}, table {r[0][2]:6.2f}, table + cost-ordered {ordered:6.2f})   "
           f"fast {r[1][0]:7.2f} ms (no-vol {r[1][1]:6.2f}, table {r[1][2]:6.2f})", flush=True)
