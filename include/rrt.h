@@ -264,6 +264,17 @@ int rrt_launch_raymarch_ex(void* d_out_rgba8, int width, int height, float time,
  *      tests against the oracle (device pointers, n elements, xyz interleaved). ---- */
 int rrt_unit_geodesic_acc(int n, const float* d_p, const float* d_v, float spin, float* d_out, void* stream);
 int rrt_unit_rk4(int n, float* d_p, float* d_v, const float* d_h, float spin, void* stream);
+/* the PRODUCTION RK4 step (csrc/rrt_device.h: integrate_rk4_lean -- what the render kernels run instead of the
+ * literal integrators.h:23-59) as a chain of n_steps steps per element, driven as the march drives it: loop-top radius
+ * from the seed pair the previous step handed on, v_rsq fall-back on a rejected seed, horizon test (a ray whose
+ * loop-top radius is < 2.02 stops; d_steps, may be NULL, receives the steps taken).  d_h == NULL: step size by the
+ * march's zone rule (raymarcher.cu:56-62) and the wave-uniform vacuum step wherever a whole wavefront (64 consecutive
+ * elements) is at r >= 30; d_h != NULL: the generic step with h = d_h[i] on every step.  seed_scale: the first root is
+ * seeded with seed_scale / r (0: no seed, like a ray's first step). */
+int rrt_unit_rk4_lean(int n, float* d_p, float* d_v, const float* d_h, float spin, int n_steps, float seed_scale,
+                      int32_t* d_steps, void* stream);
+/* the march's divide (csrc/rrt_device.h: div_seeded, one Markstein correction) on explicit operands and seeds */
+int rrt_unit_div_seeded(int n, const float* d_a, const float* d_b, const float* d_seed, float* d_out, void* stream);
 int rrt_unit_hash31(int n, const float* d_p, float* d_out, void* stream);
 int rrt_unit_noise3d(int n, const float* d_p, float* d_out, void* stream);
 int rrt_unit_fbm(int n, const float* d_p, int octaves, float* d_out, void* stream);
@@ -292,6 +303,10 @@ int rrt_unit_media_lut(int n, const float* d_p, float time, int table, float* d_
  * [0] receives the number of mismatching cases, [1..3] one failing case. */
 int rrt_selfcheck_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* stream);
 int rrt_selfcheck_div(unsigned long long n_cases, uint32_t seed, unsigned long long* d_counters, void* stream);
+/* the same two divides with reciprocal-root seeds as the march itself produces them: out of sqrt_seeded_yh<1> / <2>
+ * started from estimates off by up to each form's acceptance tolerance (extrapolated seeds included); rejected roots are
+ * skipped; d_counters[3] receives the number of divides checked */
+int rrt_selfcheck_div_march(unsigned long long n_cases, uint32_t seed, unsigned long long* d_counters, void* stream);
 /* the march's transcendental-free square root (csrc/rrt_device.h: sqrt_seeded) over a range of float bit patterns
  * and a ladder of seed errors; d_counters[3] receives the number of accepted (checked) cases */
 int rrt_selfcheck_sqrt_seeded(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* stream);

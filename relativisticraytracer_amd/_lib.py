@@ -90,6 +90,8 @@ SYMBOLS = [
                                     C.POINTER(rrt_debug_outputs), _vp]),
     ("rrt_unit_geodesic_acc", _i, [_i, _vp, _vp, _f, _vp, _vp]),
     ("rrt_unit_rk4", _i, [_i, _vp, _vp, _vp, _f, _vp]),
+    ("rrt_unit_rk4_lean", _i, [_i, _vp, _vp, _vp, _f, _i, _f, _vp, _vp]),
+    ("rrt_unit_div_seeded", _i, [_i, _vp, _vp, _vp, _vp, _vp]),
     ("rrt_unit_hash31", _i, [_i, _vp, _vp, _vp]),
     ("rrt_unit_noise3d", _i, [_i, _vp, _vp, _vp]),
     ("rrt_unit_fbm", _i, [_i, _vp, _i, _vp, _vp]),
@@ -106,6 +108,7 @@ SYMBOLS = [
     ("rrt_unit_media_lut", _i, [_i, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     ("rrt_selfcheck_sqrt", _i, [C.c_uint32, C.c_uint32, _vp, _vp]),
     ("rrt_selfcheck_div", _i, [_ull, C.c_uint32, _vp, _vp]),
+    ("rrt_selfcheck_div_march", _i, [_ull, C.c_uint32, _vp, _vp]),
     ("rrt_selfcheck_div_tame", _i, [_ull, C.c_uint32, _vp, _vp]),
     ("rrt_selfcheck_div_const", _i, [C.c_uint32, C.c_uint32, _vp, _vp]),
     ("rrt_selfcheck_sqrt_seeded", _i, [C.c_uint32, C.c_uint32, _vp, _vp]),

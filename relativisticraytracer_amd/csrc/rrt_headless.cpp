@@ -6,6 +6,7 @@
 //
 //   rrt_headless --width 1000 --height 700 --frames 24 --path 0 --spin 0.9 --out frames.rgba [--sky-seed 1]
 //                [--gpus N] [--tile-rows 16] [--workspace-gib G] [--noise-table-gib B | --no-noise-table]
+//                [--init-timeout 300] [--frame-timeout 120]      (watchdog, seconds; exit status 3 when it fires)
 //
 // Noise tables: the reference's simTime runs without bound (main.cpp:515) and a table's size grows with the times
 // it covers, so each device keeps ONE table over a window of the clock that fits --noise-table-gib (default 2;
@@ -24,12 +25,19 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rrt.h"
@@ -66,16 +74,89 @@ std::vector<uint8_t> synthetic_sky(int w, int h, int seed) {
     return out;
 }
 
-// RRT_HEADLESS_TRACE=1: timestamped progress lines on stderr (set by the tests, so that a hang -- e.g. inside a
-// communicator bring-up on a sick node -- says where it sat when the harness kills the run)
+// Progress trace + watchdog.  Every phase of the driver passes a trace point; the last kTraceKeep of them are kept in
+// memory (RRT_HEADLESS_TRACE=1 also prints them as they happen).  A watchdog thread looks at the time since the last
+// trace point: it says on stderr every 30 s where the driver is waiting, and once the wait exceeds the limit of the
+// phase (--init-timeout for the bring-up -- communicator included --, --frame-timeout once frames are being rendered) it
+// prints the kept trace and every communicator's ncclCommGetAsyncError and _exit()s with status 3: a sick node or a stuck
+// collective ends the run with a diagnosis instead of hanging it (no retry, nothing is re-executed).
+// Why the bring-up gets its own, longer limit: /opt/rocm/lib/librccl.so is a 573 MB fat binary; the first collective of a
+// process page-faults the gfx950 code object out of it, which took minutes on a box with a cold page cache (the one
+// abnormal end of round 3) -- warm_library_pages() below turns that into one sequential read.
+constexpr int kTraceKeep = 96;
+struct TraceState {
+    std::mutex mu;
+    std::string lines[kTraceKeep];
+    unsigned long long n = 0;
+    std::atomic<long long> last_ns{0};
+    std::atomic<const char*> phase{"start-up"};
+    std::atomic<bool> in_frames{false}, stop{false};
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::vector<ncclComm_t> comms;              // filled once, before in_frames (read by the watchdog on expiry only)
+};
+TraceState g_tr;
+
+long long now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - g_tr.t0).count();
+}
 void trace(const char* what, int k = -1) {
     static const bool on = getenv("RRT_HEADLESS_TRACE") != nullptr;
-    if (!on) return;
-    static const auto t0 = std::chrono::steady_clock::now();
-    const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (k >= 0) fprintf(stderr, "[rrt_headless %8.3f s] %s %d\n", t, what, k);
-    else fprintf(stderr, "[rrt_headless %8.3f s] %s\n", t, what);
-    fflush(stderr);
+    const long long t = now_ns();
+    char buf[160];
+    if (k >= 0) snprintf(buf, sizeof(buf), "[rrt_headless %8.3f s] %s %d", t * 1e-9, what, k);
+    else snprintf(buf, sizeof(buf), "[rrt_headless %8.3f s] %s", t * 1e-9, what);
+    {
+        std::lock_guard<std::mutex> lk(g_tr.mu);
+        g_tr.lines[g_tr.n++ % kTraceKeep] = buf;
+    }
+    g_tr.phase.store(what);
+    g_tr.last_ns.store(t);
+    if (on) { fprintf(stderr, "%s\n", buf); fflush(stderr); }
+}
+void dump_trace() {
+    std::lock_guard<std::mutex> lk(g_tr.mu);
+    const unsigned long long first = g_tr.n > kTraceKeep ? g_tr.n - kTraceKeep : 0;
+    for (unsigned long long i = first; i < g_tr.n; ++i) fprintf(stderr, "  %s\n", g_tr.lines[i % kTraceKeep].c_str());
+}
+void watchdog(double init_limit_s, double frame_limit_s) {
+    long long said = 0;
+    while (!g_tr.stop.load()) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(200));
+        const long long idle = now_ns() - g_tr.last_ns.load();
+        const double limit = g_tr.in_frames.load() ? frame_limit_s : init_limit_s;
+        if (idle > (said + 1) * 30000000000ll) {
+            ++said;
+            fprintf(stderr, "rrt_headless: %.0f s in \"%s\" (limit %.0f s)\n", idle * 1e-9, g_tr.phase.load(), limit);
+            fflush(stderr);
+        }
+        if (idle < 30000000000ll) said = 0;
+        if (limit > 0.0 && idle * 1e-9 > limit) {
+            fprintf(stderr, "rrt_headless: no progress for %.0f s in \"%s\" -- giving up.  Last trace points:\n", idle * 1e-9,
+                    g_tr.phase.load());
+            dump_trace();
+            for (size_t d = 0; d < g_tr.comms.size(); ++d) {
+                ncclResult_t async = ncclSuccess;
+                const ncclResult_t q = ncclCommGetAsyncError(g_tr.comms[d], &async);
+                fprintf(stderr, "  communicator %zu: ncclCommGetAsyncError -> %s, async error: %s\n", d, ncclGetErrorString(q),
+                        ncclGetErrorString(async));
+            }
+            fflush(stderr);
+            _exit(3);
+        }
+    }
+}
+
+// Read a shared library's file once, front to back, so that its pages are in the page cache before the loader / the HIP
+// runtime fault them in one by one (on a cold overlay file system the page-by-page path is the slow one).
+void warm_library_pages(const void* symbol_in_library) {
+    Dl_info info;
+    if (!dladdr(symbol_in_library, &info) || !info.dli_fname) return;
+    const int fd = open(info.dli_fname, O_RDONLY);
+    if (fd < 0) return;
+    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    std::vector<char> buf(8u << 20);
+    while (read(fd, buf.data(), buf.size()) > 0) {}
+    close(fd);
 }
 
 int fail(const char* what, int rc) {
@@ -106,6 +187,8 @@ struct Device {                // everything one GPU owns
     void* tiles[kMaxSlots] = {};                  // this device's shard of a frame
     int shard_rows = 0;
     ncclComm_t comm = nullptr;
+    void* probe = nullptr;                        // 256 B to send + 256 B per peer to receive: the bring-up exchange
+    hipEvent_t comm_free = nullptr;               // after this device's part of the last exchange (orders the next one behind it)
 };
 
 }  // namespace
@@ -119,6 +202,7 @@ int main(int argc, char** argv) {
                                    // wavefronts; 3 measured best at 8 shards of a 4K frame: profiles/r02_frames_in_flight.txt)
     float spin = 0.0f;
     double table_gib = 2.0;
+    double init_timeout = 300.0, frame_timeout = 120.0;       // watchdog limits in seconds (0: none)
     std::string out_path;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -129,6 +213,8 @@ int main(int argc, char** argv) {
         else if (a == "--frames-in-flight") val(kSlots);
         else if (a == "--spin" && i + 1 < argc) spin = (float)atof(argv[++i]);
         else if (a == "--noise-table-gib" && i + 1 < argc) table_gib = atof(argv[++i]);
+        else if (a == "--init-timeout" && i + 1 < argc) init_timeout = atof(argv[++i]);
+        else if (a == "--frame-timeout" && i + 1 < argc) frame_timeout = atof(argv[++i]);
         else if (a == "--no-noise-table") use_table = 0;
         else if (a == "--tile-order") tile_order = 1; else if (a == "--no-tile-order") tile_order = 0;
         else if (a == "--force-collective") force_collective = 1;     // run the RCCL exchange even with one GPU (self-check)
@@ -143,6 +229,18 @@ int main(int argc, char** argv) {
     if ((rc = rrt_device_count(&n_dev)) != RRT_OK) return fail("no GPU", rc);
     if (gpus > n_dev) { fprintf(stderr, "rrt_headless: --gpus %d but %d device(s) visible\n", gpus, n_dev); return 2; }
     const bool collective = gpus > 1 || force_collective;
+    trace("start");
+    std::thread dog(watchdog, init_timeout, frame_timeout);
+    struct DogStop { std::thread& t; ~DogStop() { g_tr.stop.store(true); t.join(); } } dog_stop{dog};      // every return path
+    // the RCCL library's pages, read sequentially in the background while the per-device resources are set up
+    std::thread warm;
+    if (collective && !getenv("RRT_NO_LIBRARY_WARMUP")) warm = std::thread(warm_library_pages, (const void*)&ncclCommInitAll);
+    struct WarmJoin { std::thread& t; ~WarmJoin() { if (t.joinable()) t.join(); } } warm_join{warm};
+    // a failing communicator says why (RCCL prints nothing below WARN); the caller's setting wins
+    if (collective) setenv("NCCL_DEBUG", "WARN", 0);
+    // one process, one node: RCCL's bootstrap and RAS sockets need no interface but the loopback (by default it picks
+    // the first non-loopback one -- in a container a veth whose state is not this program's business)
+    if (collective) setenv("NCCL_SOCKET_IFNAME", "lo", 0);
 
     // the recording clock (main.cpp:511-516) says which times the sequence reaches; the tables slide along it
     float seq_end = 0.0f;
@@ -172,6 +270,8 @@ int main(int argc, char** argv) {
         D.id = d;
         HIPCHK(hipSetDevice(d));
         if ((rc = rrt_sky_create(sky.data(), 2048, 1024, &D.sky)) != RRT_OK) return fail("sky", rc);
+        HIPCHK(hipMalloc(&D.probe, 256 * (size_t)(gpus + 1)));
+        HIPCHK(hipEventCreateWithFlags(&D.comm_free, hipEventDisableTiming));
         for (int s = 0; s < kSlots; ++s) {
             HIPCHK(hipStreamCreateWithFlags(&D.stream[s], hipStreamNonBlocking));
             HIPCHK(hipMalloc(&D.tiles[s], shard_stride));
@@ -188,10 +288,23 @@ int main(int argc, char** argv) {
         std::vector<int> ids(gpus);
         std::vector<ncclComm_t> comms(gpus);
         for (int d = 0; d < gpus; ++d) ids[d] = d;
+        if (warm.joinable()) { trace("waiting for the RCCL library pages"); warm.join(); }
         trace("ncclCommInitAll ...");
         NCCLCHK(ncclCommInitAll(comms.data(), gpus, ids.data()));
         trace("ncclCommInitAll done");
         for (int d = 0; d < gpus; ++d) dev[d].comm = comms[d];
+        g_tr.comms = comms;
+        // One untimed exchange of a few bytes brings up the peer-to-peer channels and loads RCCL's code object now, under
+        // the bring-up limit, instead of under frame 1's.
+        trace("first exchange (channel set-up) ...");
+        NCCLCHK(ncclGroupStart());
+        for (int d = 0; d < gpus; ++d) {
+            NCCLCHK(ncclSend(dev[d].probe, 256, ncclUint8, 0, dev[d].comm, dev[d].stream[0]));
+            NCCLCHK(ncclRecv(static_cast<uint8_t*>(dev[0].probe) + 256 * (size_t)(d + 1), 256, ncclUint8, d, dev[0].comm, dev[0].stream[0]));
+        }
+        NCCLCHK(ncclGroupEnd());
+        for (int d = 0; d < gpus; ++d) { HIPCHK(hipSetDevice(d)); HIPCHK(hipStreamSynchronize(dev[d].stream[0])); }
+        trace("first exchange done");
     }
     // device 0: gathered shards + assembled frame, per slot; pinned host frames for the sink
     HIPCHK(hipSetDevice(0));
@@ -216,14 +329,19 @@ int main(int argc, char** argv) {
     if (path >= 0 && (rc = rrt_path_info(path, &path_name, nullptr, nullptr)) != RRT_OK) return fail("path", rc);
 
     // write frame `k`'s pixels once its copy has landed (called one frame late, so that the copy overlaps the next render)
+    // (without a sink the wait still happens: the host never runs more than kSlots frames ahead of the device, a device
+    // fault is reported at the frame it belongs to, and the watchdog sees frames complete)
+    int delivered = 0;
     auto deliver = [&](int slot) -> int {
-        if (!f) return 0;
         HIPCHK(hipEventSynchronize(done[slot]));
-        if (fwrite(host[slot], 1, frame_bytes, f) != frame_bytes) fprintf(stderr, "Warning: Frame write incomplete\n");
+        trace("frame complete", ++delivered);
+        if (f && fwrite(host[slot], 1, frame_bytes, f) != frame_bytes) fprintf(stderr, "Warning: Frame write incomplete\n");
         return 0;
     };
 
     for (int d = 0; d < gpus; ++d) { HIPCHK(hipSetDevice(d)); HIPCHK(hipDeviceSynchronize()); }
+    trace("bring-up complete; rendering");
+    g_tr.in_frames.store(true);
     auto t0 = std::chrono::steady_clock::now();
     for (int k = 1; k <= frames; ++k) {
         const int slot = k % kSlots;
@@ -273,6 +391,10 @@ int main(int argc, char** argv) {
         }
         // 2. one gather: every device sends its shard, device 0 receives all of them (its own included)
         if (collective) {
+            // Successive frames use the SAME communicators from DIFFERENT streams (slot k mod kSlots).  RCCL orders the
+            // operations of one communicator by itself; the event chain states that order in the stream graph as well:
+            // a device's part of exchange k starts after its part of exchange k-1 has finished, whatever streams they ran on.
+            if (k > 1) for (int d = 0; d < gpus; ++d) { HIPCHK(hipSetDevice(d)); HIPCHK(hipStreamWaitEvent(dev[d].stream[slot], dev[d].comm_free, 0)); }
             NCCLCHK(ncclGroupStart());
             for (int d = 0; d < gpus; ++d) {
                 const size_t bytes = (size_t)dev[d].shard_rows * w * 4;
@@ -282,6 +404,7 @@ int main(int argc, char** argv) {
                                  dev[0].stream[slot]));
             }
             NCCLCHK(ncclGroupEnd());
+            for (int d = 0; d < gpus; ++d) { HIPCHK(hipSetDevice(d)); HIPCHK(hipEventRecord(dev[d].comm_free, dev[d].stream[slot])); }
             // 3. device 0 scatters the shards into the bottom-up frame
             HIPCHK(hipSetDevice(0));
             if ((rc = rrt_assemble_all_tiles(frame[slot], gathered[slot], shard_stride, w, h, tile_rows, gpus, dev[0].stream[slot])) != RRT_OK)
@@ -310,6 +433,8 @@ int main(int argc, char** argv) {
         Device& D = dev[d];
         HIPCHK(hipSetDevice(d));
         if (D.comm) ncclCommDestroy(D.comm);
+        (void)hipFree(D.probe);
+        (void)hipEventDestroy(D.comm_free);
         for (int s = 0; s < kSlots; ++s) {
             if (D.pool[s]) rrt_workspace_destroy(D.pool[s]);
             if (D.order[s]) rrt_tile_order_destroy(D.order[s]);

@@ -1011,6 +1011,61 @@ __global__ void k_rk4(int n, float* p, float* v, const float* h, float spin) {
     else integrate_rk4<false>(pp, vv, h[i], drag_c);
     st3(p, i, pp); st3(v, i, vv);
 }
+/* The PRODUCTION step (round 3's integrate_rk4_lean, what every render kernel runs) as a chain of n_steps steps per
+ * element, driven exactly as march_inline drives it: loop-top radius from the seed pair the previous step handed on
+ * (seeded Goldschmidt root, v_rsq fall-back where the seed is rejected), horizon test r < 2.02 (the ray stops; the lean
+ * step's stage 1 relies on it), then
+ *   h == NULL: the march's own zone rule for the step size (raymarcher.cu:56-62) and the wave-uniform VACUUM step when all
+ *              64 lanes of the wavefront hold an accepted radius >= 30 -- both template instances, the extrapolated
+ *              seeds and the fall-backs are exercised by the inputs of tests/test_gpu_units.py;
+ *   h != NULL: the generic step with the caller's step size on every step.
+ * seed_scale: the first loop-top root's seed is seed_scale / r (0: none, as a ray's first step; 1.3: a bad seed that must be
+ * rejected; 1.00005: an imperfect one that is accepted).  steps[i] = steps taken before the horizon test stopped the ray. */
+template <bool SPIN>
+__global__ __launch_bounds__(64) void k_rk4_lean(int n, float* p, float* v, const float* h_in, float drag_c, int n_steps,
+                                                 float seed_scale, int* steps_out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const bool valid = i < n;
+    v3 pp = valid ? ld3(p, i) : mk(1000.f, 0.f, 0.f), vv = valid ? ld3(v, i) : mk(0.f, 0.f, 0.f);
+    float ys = 0.0f, hs = 0.0f, hcp = 0.0f;
+    if (seed_scale != 0.0f) {
+        float r0, y0;
+        sqrt_rsq(dot(pp, pp), r0, y0);
+        ys = seed_scale * y0; hs = 0.5f * ys;
+    }
+    int k = 0;
+    for (; k < (valid ? n_steps : 0); ++k) {
+        const v3 rel_p = pp;
+        const float r2 = dot(rel_p, rel_p);
+        float r, y, hy;
+        const bool rejected = sqrt_seeded_yh<1>(r2, ys, hs, r, y, hy);
+        const unsigned long long rej_mask = __builtin_amdgcn_ballot_w64(rejected);
+        const bool vacuum = h_in == nullptr && RRT_VACUUM_PATH && (rej_mask | __builtin_amdgcn_ballot_w64(!(r >= kVacuumR))) == 0ull;
+        if (!vacuum && rej_mask != 0ull) {
+            bool small;
+            if (rejected) radius_fallback(r2, r, y, hy, small);
+        }
+        if (r < kEventHorizon * 1.01f) break;
+        if (vacuum) {
+            integrate_rk4_lean<SPIN, true>(pp, vv, 0.f, 0.f, 0.f, drag_c, r2, r, y, hy, ys, hs, hcp);
+        } else {
+            float h, hh, h6;
+            if (h_in) { h = h_in[i]; hh = 0.5f * h; h6 = h / 6.0f; }
+            else {
+                const bool near_bh = r < 18.0f;
+                const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
+                zone_step(near_bh, in_disk, h, hh, h6);
+            }
+            integrate_rk4_lean<SPIN, false>(pp, vv, h, hh, h6, drag_c, r2, r, y, hy, ys, hs, hcp);
+        }
+    }
+    if (valid) { st3(p, i, pp); st3(v, i, vv); if (steps_out) steps_out[i] = k; }
+}
+/* the march's divide on explicit operands: out = div_seeded(a, b, seed) */
+__global__ void k_div_seeded(int n, const float* a, const float* b, const float* seed, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = div_seeded(a[i], b[i], seed[i]);
+}
 __global__ void k_hash31(int n, const float* p, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = hash31(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
@@ -1162,6 +1217,45 @@ __global__ void k_selfcheck_div(unsigned long long n, uint32_t seed, unsigned lo
         if (rrt_f2u(q2) != rrt_f2u(w2)) { ++bad; counters[1] = rrt_f2u(c); counters[2] = rrt_f2u(d2); counters[3] = 2; }
     }
     if (bad) atomicAdd(counters, (unsigned long long)bad);
+}
+
+/* The same two divides with the reciprocal-root seed AS THE MARCH PRODUCES IT (round 4): y comes out of
+ * sqrt_seeded_yh<1> / <2> started from an estimate that is off by up to the acceptance tolerance of each form (uniform in
+ * +-1.45e-4 for the one-iteration root -- which also covers the linearly extrapolated seeds of the vacuum step --, +-8.9e-3
+ * for the two-iteration one), not out of the v_rsq-based sqrt_rsq that k_selfcheck_div uses: such a y carries up to 1.5 e^2 =
+ * 3.4e-8 of its own error into y^3 and y^5, i.e. the Markstein cores start from a seed ~1.7x worse than k_selfcheck_div's.
+ * Rejected roots are skipped (the march takes the sqrt_rsq fall-back there).  counters[0] += mismatches, [1]/[2] one failing
+ * case (numerator, denominator bits), [3] += checked divides. */
+__global__ void k_selfcheck_div_march(unsigned long long n, uint32_t seed, unsigned long long* counters) {
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned bad = 0;
+    unsigned long long checked = 0;
+    for (uint64_t k = idx; k < n; k += stride) {
+        uint32_t h1 = mix32((uint32_t)k * 2654435761u + seed), h2 = mix32(h1 ^ (uint32_t)(k >> 32) ^ 0x9e3779b9u);
+        uint32_t h3 = mix32(h2 + 0x85ebca6bu), h4 = mix32(h3 ^ 0xc2b2ae35u);
+        float r2 = rrt_u2f(0x3f800000u + (h1 % (28u << 23)));                 /* [1, 2^28) */
+        float num = rrt_u2f(((87u << 23) + (h2 % (80u << 23))) | (h3 & 0x80000000u));   /* +-2^[-40,40) */
+        float c = rrt_u2f(0x3f000000u + (h3 & 0x01ffffffu));                 /* [0.5, 8): drag constants */
+        float r_ref, y_ref;
+        sqrt_rsq(r2, r_ref, y_ref);
+        const bool two = (h4 & 1u) != 0;
+        const float u = (float)((h4 >> 8) & 0xffffffu) * (2.0f / 16777216.0f) - 1.0f;      /* [-1, 1) */
+        const float y0 = y_ref * (1.0f + u * (two ? 8.9e-3f : 1.45e-4f));
+        float r, y, hy;
+        const bool rejected = two ? sqrt_seeded_yh<2>(r2, y0, 0.5f * y0, r, y, hy) : sqrt_seeded_yh<1>(r2, y0, 0.5f * y0, r, y, hy);
+        if (rejected) continue;
+        if (rrt_f2u(r) != rrt_f2u(r_ref)) { ++bad; counters[1] = rrt_f2u(r2); counters[2] = rrt_f2u(y0); continue; }
+        float y2 = y * y, y3 = y2 * y;
+        float d2 = r2 * r, d1 = (r2 * r2) * r;
+        float q1 = div_seeded(num, d1, y3 * y2), q2 = div_seeded(c, d2, y3);
+        float w1 = num / d1, w2 = c / d2;
+        checked += 2;
+        if (rrt_f2u(q1) != rrt_f2u(w1)) { ++bad; counters[1] = rrt_f2u(num); counters[2] = rrt_f2u(d1); }
+        if (rrt_f2u(q2) != rrt_f2u(w2)) { ++bad; counters[1] = rrt_f2u(c); counters[2] = rrt_f2u(d2); }
+    }
+    if (bad) atomicAdd(counters, (unsigned long long)bad);
+    atomicAdd(counters + 3, checked);
 }
 
 /* sqrt_seeded against sqrtf: every float whose bits lie in [lo, hi), with estimates of 1/sqrt(x) that are off by
@@ -1930,6 +2024,20 @@ int rrt_unit_rk4(int n, float* p, float* v, const float* h, float spin, void* st
     if (n > 0 && (!p || !v || !h)) return RRT_ERR_INVALID_ARGUMENT;
     return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_rk4, g, b, 0, s, n, p, v, h, spin); });
 }
+int rrt_unit_rk4_lean(int n, float* p, float* v, const float* h, float spin, int n_steps, float seed_scale, int32_t* steps, void* st) {
+    if (n < 0 || n_steps < 0 || (n > 0 && (!p || !v)) || !(seed_scale == seed_scale)) return RRT_ERR_INVALID_ARGUMENT;
+    if (n == 0) return RRT_OK;
+    const float drag_c = (2.0f * spin) * 2.0f;
+    const dim3 g((n + 63) / 64), b(64);                     /* one wavefront per workgroup, like the render kernels */
+    if (spin != 0.0f) hipLaunchKernelGGL((k_rk4_lean<true>), g, b, 0, static_cast<hipStream_t>(st), n, p, v, h, drag_c, n_steps, seed_scale, steps);
+    else hipLaunchKernelGGL((k_rk4_lean<false>), g, b, 0, static_cast<hipStream_t>(st), n, p, v, h, drag_c, n_steps, seed_scale, steps);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+int rrt_unit_div_seeded(int n, const float* a, const float* b, const float* seed, float* out, void* st) {
+    if (n > 0 && (!a || !b || !seed || !out)) return RRT_ERR_INVALID_ARGUMENT;
+    return unit_launch(n, st, [&](dim3 g, dim3 bl, hipStream_t s) { hipLaunchKernelGGL(k_div_seeded, g, bl, 0, s, n, a, b, seed, out); });
+}
 int rrt_unit_hash31(int n, const float* p, float* out, void* st) {
     if (n > 0 && (!p || !out)) return RRT_ERR_INVALID_ARGUMENT;
     return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_hash31, g, b, 0, s, n, p, out); });
@@ -2040,6 +2148,12 @@ int rrt_selfcheck_sqrt_seeded(uint32_t lo_bits, uint32_t hi_bits, unsigned long 
 int rrt_selfcheck_div_tame(unsigned long long n, uint32_t seed, unsigned long long* d_counters, void* st) {
     if (!d_counters) return RRT_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(k_selfcheck_div_tame, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(st), n, seed, d_counters);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+int rrt_selfcheck_div_march(unsigned long long n, uint32_t seed, unsigned long long* d_counters, void* st) {
+    if (!d_counters) return RRT_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(k_selfcheck_div_march, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(st), n, seed, d_counters);
     RRT_HIP(hipGetLastError());
     return RRT_OK;
 }

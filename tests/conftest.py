@@ -29,6 +29,12 @@ def units_ref():
 
 
 @pytest.fixture(scope="session")
+def rk4_chain_ref():
+    """50-step chains of the reference's own integrate_rk4 under the march's step-size rule (make_golden.py::make_rk4_chains)."""
+    return dict(np.load(os.path.join(GOLDEN, "rk4_chain_ref.npz")))
+
+
+@pytest.fixture(scope="session")
 def frames_gold():
     return dict(np.load(os.path.join(GOLDEN, "frames_oracle.npz")))
 

@@ -26,6 +26,12 @@ stays clear:
                      modes, with per-ray diagnostics the reference kernel does not output
                      (final p / vel / radiance, float RGB): regression pins + GPU comparison data.
 
+  rk4_chain_ref.npz  50-step chains of the REFERENCE's own integrate_rk4 (integrators.h:23-59, libref_units.so)
+                     under the march's zone rule for the step size and its horizon test (raymarcher.cu:42-64),
+                     a in {0, 0.9, 0.99}: states after {1, 2, 3, 5, 10, 25, 50} steps.  Pins the PRODUCTION step of the
+                     HIP kernels (integrate_rk4_lean: seed pairs carried from step to step, wave-uniform vacuum step,
+                     extrapolated seeds, v_rsq fall-backs) at unit level: rrt_unit_rk4_lean, tests/test_gpu_units.py.
+
     python tests/golden/make_golden.py
 """
 import os
@@ -109,6 +115,67 @@ def make_units():
     out["bloom_t0.8"] = ref.bloom(d["rgb"], 0.8)
     np.savez_compressed(os.path.join(HERE, "units_ref.npz"), **out)
     print("units_ref.npz:", len(out), "arrays")
+
+
+CHAIN_MARKS = (1, 2, 3, 5, 10, 25, 50)
+
+
+def chain_inputs():
+    """512 start states in wave-aligned groups of 64 (the vacuum step is taken per WAVEFRONT): 4 waves far out (all
+    lanes stay at r >= 30 for 50 steps: vacuum step, extrapolated seeds), 1 wave straddling r = 30, 1 in the disk zone,
+    1 near the hole (plunging rays stop at the horizon test), 1 log-uniform mix."""
+    rng = np.random.default_rng(20261004)
+    n = 512
+    dirs = rng.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    r = np.empty(n)
+    r[:256] = rng.uniform(60.0, 240.0, 256)
+    r[256:320] = rng.uniform(28.0, 36.0, 64)
+    r[320:384] = rng.uniform(19.0, 29.0, 64)
+    r[384:448] = rng.uniform(2.5, 17.0, 64)
+    r[448:] = np.exp(rng.uniform(np.log(2.1), np.log(300.0), 64))
+    p = dirs * r[:, None]
+    p[320:384, 1] = rng.uniform(-3.9, 3.9, 64)                       # inside |y| < 4: the disk zone's step size
+    v = rng.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v[384:416] = -dirs[384:416] + 0.3 * v[384:416]                    # half of the near-hole wave heads inwards
+    v *= rng.uniform(0.9, 1.1, (n, 1))
+    return p.astype(np.float32), v.astype(np.float32)
+
+
+def march_step_size(p):
+    """raymarcher.cu:42-62 in binary32: (alive = passes the horizon test, h by zone)."""
+    f = np.float32
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    r = np.sqrt((x * x + y * y) + z * z)                              # dot() of math_utils.h, sqrtf
+    alive = ~(r < f(2.0) * f(1.01))
+    near = r < f(18.0)
+    disk = (np.abs(y) < f(0.8) * f(5.0)) & (r < f(25.0) + f(5.0))
+    h = np.where(near, f(0.3) * f(0.1), np.where(disk, f(0.3) * f(0.3), f(0.3))).astype(np.float32)
+    return alive, h
+
+
+def make_rk4_chains():
+    if not po.ref_available():
+        po.build(ref=True)
+    ref = po.ref_units()
+    p0, v0 = chain_inputs()
+    out = {"p0": p0, "v0": v0, "marks": np.int32(CHAIN_MARKS)}
+    for a in SPINS:
+        p, v = p0.copy(), v0.copy()
+        steps = np.zeros(len(p), np.int32)
+        live = np.ones(len(p), bool)
+        for k in range(1, max(CHAIN_MARKS) + 1):
+            alive, h = march_step_size(p)
+            live &= alive                                             # a ray that met the horizon test stays where it is
+            pn, vn = ref.rk4(p[live], v[live], h[live], a)
+            p[live], v[live] = pn, vn
+            steps[live] += 1
+            if k in CHAIN_MARKS:
+                out[f"p_a{a:g}_k{k}"], out[f"v_a{a:g}_k{k}"] = p.copy(), v.copy()
+                out[f"steps_a{a:g}_k{k}"] = steps.copy()
+        print(f"rk4 chain a={a:g}: {int((~live).sum())} rays stopped at the horizon test, "
+              f"{int((np.linalg.norm(p[:256], axis=1) < 30).sum())} far-out rays came inside r = 30")
+    np.savez_compressed(os.path.join(HERE, "rk4_chain_ref.npz"), **out)
+    print("rk4_chain_ref.npz:", len(out), "arrays")
 
 
 def make_camera():
@@ -227,7 +294,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "frames_ref":
         make_frames_ref()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rk4_chains":
+        make_rk4_chains()
+        sys.exit(0)
     make_units()
     make_camera()
     make_frames()
     make_frames_ref()
+    make_rk4_chains()

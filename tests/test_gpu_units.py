@@ -41,6 +41,43 @@ def test_rk4_matches_reference_vectors(g, units_ref, spin):
     assert same_bits(g.host(v), units_ref[f"rk4_v_a{spin:g}"])
 
 
+@pytest.mark.parametrize("spin", SPINS)
+def test_production_rk4_step_matches_reference_vectors(g, units_ref, spin):
+    """integrate_rk4_lean -- the step every render kernel runs (seeded Goldschmidt roots, one-correction Markstein
+    divides, guards behind the fall-back) -- on the reference's one-step vectors, with no seed, a good seed, an
+    imperfect seed that is accepted and a bad one that must be rejected.  The lean step's precondition is the march's:
+    the loop-top radius has passed the horizon test (r >= 2.02), so the vectors inside it are left to `rrt_unit_rk4`."""
+    import torch
+    r = np.linalg.norm(units_ref["geo_p"].astype(np.float64), axis=1)
+    sel = r > 2.03
+    assert sel.sum() > 900
+    for seed_scale in (0.0, 1.0, 1.00005, 0.9999, 1.3, 0.5):
+        p, v, h = g.dev(units_ref["geo_p"][sel]), g.dev(units_ref["geo_v"][sel]), g.dev(units_ref["rk4_h"][sel])
+        steps = torch.zeros(int(sel.sum()), dtype=torch.int32, device="cuda")
+        g.unit("rk4_lean", int(sel.sum()), p, v, h, float(spin), 1, float(seed_scale), steps)
+        assert same_bits(g.host(p), units_ref[f"rk4_p_a{spin:g}"][sel]), seed_scale
+        assert same_bits(g.host(v), units_ref[f"rk4_v_a{spin:g}"][sel]), seed_scale
+        assert (g.host(steps) == 1).all()
+
+
+@pytest.mark.parametrize("spin", SPINS)
+def test_production_rk4_chain_matches_the_reference_chain(g, rk4_chain_ref, spin):
+    """50 steps of the production step, driven as the march drives it (zone rule, wave-uniform vacuum step with
+    extrapolated seeds on the four far-out wavefronts, generic step elsewhere, seeds carried from step to step,
+    horizon test), against chains of the REFERENCE's integrate_rk4 (integrators.h:23-59): bit-exact at every mark."""
+    import torch
+    c = rk4_chain_ref
+    n = len(c["p0"])
+    for seed_scale in (0.0, 1.3):
+        for k in (int(m) for m in c["marks"]):
+            p, v = g.dev(c["p0"]), g.dev(c["v0"])
+            steps = torch.zeros(n, dtype=torch.int32, device="cuda")
+            g.unit("rk4_lean", n, p, v, None, float(spin), k, float(seed_scale), steps)
+            assert same_bits(g.host(p), c[f"p_a{spin:g}_k{k}"]), (k, seed_scale)
+            assert same_bits(g.host(v), c[f"v_a{spin:g}_k{k}"]), (k, seed_scale)
+            assert np.array_equal(g.host(steps), c[f"steps_a{spin:g}_k{k}"]), (k, seed_scale)
+
+
 def test_hash_noise_fbm_match_reference_vectors(g, units_ref):
     import torch
     n = len(units_ref["lattice"])
@@ -279,6 +316,52 @@ def test_fast_divide_is_correctly_rounded_on_march_operands(g):
     _lib.check(_lib.load().rrt_selfcheck_div(1 << 35, 12345, C.c_void_p(cnt.data_ptr()), None), "selfcheck_div")
     torch.cuda.synchronize()
     assert int(cnt[0]) == 0, f"{int(cnt[0])} mismatches, e.g. {int(cnt[1]):#x} / {int(cnt[2]):#x}"
+
+
+def test_divide_with_the_marchs_own_seeds(g):
+    """The same divides with the reciprocal root as the march produces it (round 4): out of the seeded Goldschmidt roots
+    sqrt_seeded_yh<1> / <2>, started from estimates off by up to each form's acceptance tolerance, instead of out of the
+    v_rsq-based root of the test above -- the one-correction Markstein core gets seeds about 1.7x worse than there.  2^33
+    operand sets; a one-off run of 2^42 is recorded in profiles/r04_div_march_seeds_probe.txt."""
+    import ctypes as C
+    import torch
+    from relativisticraytracer_amd import _lib
+    cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
+    _lib.check(_lib.load().rrt_selfcheck_div_march(1 << 33, 2026, C.c_void_p(cnt.data_ptr()), None), "selfcheck_div_march")
+    torch.cuda.synchronize()
+    assert int(cnt[0]) == 0, f"{int(cnt[0])} mismatches, e.g. {int(cnt[1]):#x} / {int(cnt[2]):#x}"
+    assert int(cnt[3]) > 1.5 * (1 << 33), int(cnt[3])              # most roots were accepted, two divides each
+
+
+def test_divide_known_exception_is_what_the_documents_say(g):
+    """"Bit-exact division" has ONE documented hole (rrt_device.h: div_seeded): a denominator whose
+    significand lies an odd number of ulps d <= ~11 below 2 has a reciprocal within d^2/4 * 2^-46 of a rounding tie, closer
+    than the 2^-42 the once-refined reciprocal carries, so the refined reciprocal can come out one ulp low and the quotient
+    with it.  Measured rate on march-shaped operands: 2 in 3.5e13 divides (profiles/r03_div_rounds_probe.txt) = 5.7e-14 per
+    divide, 0.004 per 4K frame.  The operand set that probe recorded -- 0x33666662 / 0x4bfffffb -- reproduces with a seed
+    three ulps (2^-21.4: march quality) off the reciprocal and not with a seed within one ulp: pinned here so that any
+    change of div_seeded that moves this behaviour is noticed."""
+    import torch
+    a = np.array([0x33666662] * 4, np.uint32).view(np.float32)
+    b = np.array([0x4bfffffb] * 4, np.uint32).view(np.float32)
+    seed = np.array([0x33000003, 0x33000004, 0x33000002, 0x33000006], np.uint32).view(np.float32)
+    out = torch.empty(4, device="cuda")
+    g.unit("div_seeded", 4, g.dev(a), g.dev(b), g.dev(seed), out)
+    got = g.host(out).view(np.uint32)
+    ieee = (a / b).view(np.uint32)
+    assert ieee[0] == 0x26e66667
+    assert np.array_equal(got[:3], ieee[:3])                          # seeds within one ulp of 1/b: the IEEE quotient
+    assert got[3] == 0x26e66666                                       # the documented exception: one ulp low
+    # and the rule away from those denominators: march-quality seeds give the IEEE quotient
+    rng = np.random.default_rng(5)
+    n = 1 << 20
+    bb = rng.uniform(1.0, 2.0, n).astype(np.float32) * np.float32(2.0) ** rng.integers(-20, 60, n).astype(np.float32)
+    aa = (rng.uniform(1.0, 2.0, n) * 2.0 ** rng.integers(-40, 40, n) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    sd = ((1.0 / bb.astype(np.float64)) * (1.0 + rng.uniform(-4e-7, 4e-7, n))).astype(np.float32)
+    far = (bb.view(np.uint32) & 0x7fffff) < 0x7fffe0                  # significand more than 32 ulps below 2
+    out = torch.empty(n, device="cuda")
+    g.unit("div_seeded", n, g.dev(aa), g.dev(bb), g.dev(sd), out)
+    assert np.array_equal(g.host(out).view(np.uint32)[far], (aa / bb).view(np.uint32)[far])
 
 
 def test_seeded_sqrt_is_correctly_rounded_whenever_it_accepts(g):

@@ -36,6 +36,31 @@ def test_rk4_step(po, units_ref, spin):
     assert same_bits(v, units_ref[f"rk4_v_a{spin:g}"])
 
 
+@pytest.mark.parametrize("spin", SPINS)
+def test_rk4_chain_of_fifty_steps(po, rk4_chain_ref, spin):
+    """The restatement's integrate_rk4 under the march's zone rule and horizon test (restated here in numpy binary32)
+    reproduces the reference's 50-step chains bit for bit at every recorded step."""
+    f = np.float32
+    c = rk4_chain_ref
+    p, v = c["p0"].copy(), c["v0"].copy()
+    live = np.ones(len(p), bool)
+    steps = np.zeros(len(p), np.int32)
+    marks = set(int(k) for k in c["marks"])
+    for k in range(1, max(marks) + 1):
+        x, y, z = p[:, 0], p[:, 1], p[:, 2]
+        r = np.sqrt((x * x + y * y) + z * z)
+        live &= ~(r < f(2.0) * f(1.01))
+        h = np.where(r < f(18.0), f(0.3) * f(0.1),
+                     np.where((np.abs(y) < f(0.8) * f(5.0)) & (r < f(25.0) + f(5.0)), f(0.3) * f(0.3), f(0.3))).astype(np.float32)
+        pn, vn = po.units().rk4(p[live], v[live], h[live], spin)
+        p[live], v[live] = pn, vn
+        steps[live] += 1
+        if k in marks:
+            assert same_bits(p, c[f"p_a{spin:g}_k{k}"]) and same_bits(v, c[f"v_a{spin:g}_k{k}"]), k
+            assert np.array_equal(steps, c[f"steps_a{spin:g}_k{k}"])
+    assert (~live).sum() >= 3 and live[:256].all()      # some rays meet the horizon test; the far-out waves never do
+
+
 def test_hash31_lattice(po, units_ref):
     got = po.units().hash31(units_ref["lattice"])
     assert np.array_equal(got.view(np.uint32), units_ref["hash31"].view(np.uint32))
