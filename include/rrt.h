@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 3      /* 3: rrt_params.tile_order, rrt_tile_order_* */
+#define RRT_ABI_VERSION 4      /* 4: rrt_params.struct_size (leading) and .pool_rounds, rrt_tile_map_*, rrt_probe_tile_costs,
+                                     rrt_clock_probe; 3: rrt_params.tile_order, rrt_tile_order_* */
 
 typedef enum {
     RRT_OK = 0,
@@ -42,7 +43,8 @@ typedef enum {
     RRT_ERR_NO_DEVICE = 2,
     RRT_ERR_HIP = 3,          /* a HIP runtime call failed; see rrt_last_hip_error() */
     RRT_ERR_BAD_HANDLE = 4,
-    RRT_ERR_OUT_OF_MEMORY = 5
+    RRT_ERR_OUT_OF_MEMORY = 5,
+    RRT_ERR_ABI_MISMATCH = 6  /* an rrt_params whose struct_size is not this library's: built against another include/rrt.h */
 } rrt_status;
 
 /* Camera basis handed to the kernel.  Layout == reference `struct CameraState`
@@ -73,6 +75,10 @@ typedef struct rrt_effects {
  * constants (include/config.h:18-48); `spin` replaces the SPIN_A macro
  * (config.h:21) so that Kerr a=0.9 / 0.99 are run-time settings. */
 typedef struct rrt_params {
+    uint32_t struct_size;    /* sizeof(rrt_params) of the header the caller was compiled against; rrt_params_default()
+                                fills it in and every entry point that takes an rrt_params refuses another value with
+                                RRT_ERR_ABI_MISMATCH (objects built against the ABI <= 3 header, whose struct began with
+                                `spin`, must be recompiled)                                              */
     float spin;              /* SPIN_A            config.h:21  default 0.0  */
     int32_t max_steps;       /* MAX_STEPS         config.h:48  default 2000 */
     int32_t volumetrics;     /* 1 = full disk + dust (reference behaviour);
@@ -98,14 +104,22 @@ typedef struct rrt_params {
                                 An rrt_noise_table id: the low octaves of the disk / dust noise read the corner
                                 hashes from a precomputed lattice table whenever the 64 rays of a wavefront
                                 share a few lattice cells (4K / 8K frames: most of them) -- same bits, about
-                                half the media cost.  Ignored when `time` lies outside
-                                the table's [0, t_max].                                                   */
+                                half the media cost.  A launch whose `time` lies outside
+                                the table's window [t0, t1] (rrt_noise_table_window) hashes arithmetically.  */
     int32_t tile_order;      /* 0 (default): wave tiles are dispatched in the static order (row blocks from the middle
                                 of the frame outwards).  An rrt_tile_order id: the launch records what every wave tile
                                 cost and the next launch of the same geometry through that object dispatches
                                 longest-first -- same pixels; removes the drain of views whose long rays are not in the
                                 middle (a 4K frame from inside the disk: 53 -> 46 ms), nothing to gain on the
-                                reference's default view.  Single-kernel path only.                           */
+                                reference's default view.  With no history for the launch's geometry the order comes
+                                from a coarse march-only probe of the same view (one ray per 16x16 pixels, run on the
+                                launch's stream right before it).  Both paths; a launch that is being captured into a
+                                hipGraph renders in the static order and leaves the object alone.              */
+    int32_t pool_rounds;     /* three-pass path: the workspace pool is reused in ROUNDS -- march until the pool is full,
+                                evaluate and composite what was pooled, resume the suspended rays -- so that any pool
+                                serves any view.  0 (default): automatic -- as many rounds as the workspace's previous
+                                launch needed, plus one, at least 2; n > 0: exactly up to n rounds.  Rays still
+                                suspended after the last round finish with the media sampled in line (same bytes).   */
 } rrt_params;
 
 #define RRT_PATH_AUTO 0
@@ -139,7 +153,9 @@ int rrt_abi_version(void);
 const char* rrt_status_string(int status);
 const char* rrt_last_hip_error(void);          /* thread-local text of the last HIP failure */
 int rrt_device_count(int* count);
-int rrt_params_default(rrt_params* prm);       /* config.h defaults                        */
+int rrt_params_default_v4(rrt_params* prm);    /* config.h defaults, struct_size = this header's sizeof(rrt_params) */
+#define rrt_params_default rrt_params_default_v4   /* (the library keeps an export of the old name that fills the 36-byte
+                                                      ABI <= 3 layout, so that a stale binary is refused, not corrupted) */
 int rrt_effects_default(rrt_effects* fx);      /* camera_settings.h:5-16 defaults          */
 
 /* ---- sky texture: replaces loadSkybox()'s cudaMallocArray + texture object,
@@ -157,6 +173,10 @@ int rrt_workspace_create(size_t bytes, int* out_id);
 int rrt_workspace_destroy(int id);
 /* after a launch has completed: rows used and wavefronts that fell back (synchronous read) */
 int rrt_workspace_stats(int id, unsigned* rows_used, unsigned* overflow_waves);
+/* rounds of the last launch (rrt_params.pool_rounds): enqueued, with work for the march, rows of the fullest round, and
+ * an upper bound of the pool's rows.  rrt_workspace_stats: rows_used = all rounds together, overflow_waves = wavefronts
+ * still suspended after the last round (finished in line). */
+int rrt_workspace_rounds(int id, unsigned* rounds_enqueued, unsigned* rounds_with_work, unsigned* peak_rows, unsigned* pool_rows);
 /* inspection: copy `bytes` of the pool starting at `offset` to host memory (synchronous) */
 int rrt_workspace_read(int id, size_t offset, size_t bytes, void* host_dst);
 
@@ -166,11 +186,17 @@ int rrt_workspace_read(int id, size_t offset, size_t bytes, void* host_dst);
  *      launch with the same width / height / row map reads.  A launch with another geometry renders in the static order
  *      and starts over.  Launches through one object are serialised on the device, also across streams: give every frame
  *      that should overlap another its own object (the headless drivers: one per slot).  Frames of an animation change
- *      little from one to the next, which is what makes the previous frame's costs a good order for this one.  The first
- *      launch of a (larger) geometry allocates the object's buffers -- a synchronising call, not for stream capture; a
- *      captured launch replays the order it was captured with (still a valid order: same pixels). ---- */
+ *      little from one to the next, which is what makes the previous frame's costs a good order for this one.  With NO
+ *      history (first launch, new geometry) the order comes from a coarse probe of the view itself: one march-only ray per
+ *      16x16 pixels on the launch's stream (~1/250 of the frame's work), costed by a fitted model -- a still image from
+ *      inside the disk gets most of the gain too; rrt_tile_order_set_seeding(id, 0) switches that off.  The first
+ *      launch of a (larger) geometry allocates the object's buffers -- a synchronising call.  A launch that is being
+ *      CAPTURED into a hipGraph ignores the object (static order, nothing recorded): a replayed graph can then never read
+ *      a permutation that a later live launch is rewriting.  Works on both paths (single kernel and three-pass). ---- */
 int rrt_tile_order_create(int* out_id);
 int rrt_tile_order_destroy(int id);
+int rrt_tile_order_set_seeding(int id, int on);
+int rrt_tile_order_seeded(int id, unsigned long long* seeded_launches);      /* launches ordered by the probe */
 /* counters; with perm_host / cost_host (either may be NULL; `capacity` elements each) also, after waiting for the
  * object's last launch, the order the next matching launch will use and the costs the last one recorded */
 int rrt_tile_order_info(int id, unsigned long long* launches, unsigned long long* ordered_launches, unsigned* n_tiles,
@@ -205,8 +231,15 @@ int rrt_noise_table_fit_window(float t_from, float t_until, size_t budget_bytes,
 
 /* Handles and devices: a sky, workspace or noise table belongs to the HIP device that was current when it was
  * created (a borrowed sky: the device that owns the pointer), and a launch or copy that names it under another
- * current device returns RRT_ERR_BAD_HANDLE.  Test hook: pretend `device` is current (< 0: ask HIP again). */
+ * current device returns RRT_ERR_BAD_HANDLE.  Test hook: pretend `device` is current (< 0: ask HIP again); it only
+ * works in a process that was started with RRT_ENABLE_TEST_HOOKS=1 in its environment (RRT_ERR_INVALID_ARGUMENT otherwise). */
 int rrt_debug_fake_device(int device);
+
+/* The shader clock the chip HOLDS, measured on the device: one wavefront sleeps for `duration_us` (<= 2 000 000) on
+ * `stream` and reads the shader-clock counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) at both ends;
+ * d_counters2[0] / d_counters2[1] * 0.1 = GHz.  Launched on a second stream beside the frames of a measurement it says what
+ * clock the roofline's peak should be priced at (bench.py: roofline.clock_ghz). */
+int rrt_clock_probe(unsigned long long* d_counters2, unsigned duration_us, void* stream);
 
 /* ---- parameters of the reference-signature entry point launch_raymarch() (include/raymarcher.h), which has
  *      no argument for them: spin, max_steps, volumetrics, a workspace, a noise table ...  NULL restores the
@@ -254,6 +287,26 @@ int rrt_assemble_tiles(void* d_frame_rgba8, const void* d_tiles, int width, int 
  * (the layout a gather into one allocation produces). */
 int rrt_assemble_all_tiles(void* d_frame_rgba8, const void* d_tiles_all, size_t shard_stride_bytes,
                            int width, int height, int tile_rows, int n_shards, void* stream);
+
+/* ---- cost-weighted tile -> shard assignment ("cost-model-weighted assignment"; the reference is
+ *      single-GPU).  The rows through the hole and the disk cost several times the sky rows; t mod n_shards evens that
+ *      out to ~9 % at 8 shards of a 4K frame, a map dealt by COST to ~1 %.  rrt_probe_tile_costs() estimates every row
+ *      tile's cost from a coarse march-only probe of the view (deterministic: every rank computes the same numbers from
+ *      the same camera, so no exchange is needed), rrt_tile_map_balance() deals the tiles longest-first to the least
+ *      loaded shard (host arithmetic), rrt_tile_map_create() makes the assignment a device-resident object, and the
+ *      two entry points below are rrt_launch_raymarch_tiles / rrt_assemble_all_tiles for such a map.  Buffer layout:
+ *      a shard's tiles in increasing t, tile-major, each tile bottom-up. ---- */
+int rrt_tile_map_create(int height, int tile_rows, int n_shards, const int32_t* shard_of_tile, int* out_id);
+int rrt_tile_map_destroy(int id);
+int rrt_tile_map_shard_rows(int id, int shard, int* rows, int* max_rows);      /* rows of `shard`'s buffer; of the largest */
+int rrt_tile_map_balance(int n_tiles, const float* tile_cost, int n_shards, int max_tiles_per_shard, int32_t* shard_of_tile_out);
+int rrt_probe_tile_costs(int width, int height, int tile_rows, float time, const rrt_camera* cam, const rrt_effects* fx,
+                         const rrt_params* prm, float* tile_cost_host, int n_tiles, void* stream);
+int rrt_launch_raymarch_tilemap(void* d_out_tiles, int width, int height, int tile_map, int shard, float time,
+                                const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx,
+                                const rrt_params* prm, void* stream);
+int rrt_assemble_all_tilemap(void* d_frame_rgba8, const void* d_tiles_all, size_t shard_stride_bytes,
+                             int width, int height, int tile_map, void* stream);
 
 /* Full-frame launch that also fills per-ray debug outputs (parity tests). */
 int rrt_launch_raymarch_ex(void* d_out_rgba8, int width, int height, float time,

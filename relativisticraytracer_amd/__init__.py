@@ -25,7 +25,8 @@ __all__ = ["CameraState", "CameraEffects", "RenderParams", "SkyTexture", "Worksp
            "set_launch_defaults", "get_launch_defaults",
            "launch_raymarch_rows", "launch_raymarch_tiles", "assemble_tiles", "assemble_all_tiles",
            "tile_shard_rows",
-           "launch_raymarch_debug", "RRTError", "device_count", "abi_version", "TileOrder"]
+           "launch_raymarch_debug", "RRTError", "device_count", "abi_version", "TileOrder", "TileMap",
+           "probe_tile_costs", "balance_tiles", "launch_raymarch_tilemap", "assemble_all_tilemap", "clock_probe_ghz"]
 
 
 def _ptr(x):
@@ -114,7 +115,7 @@ class RenderParams(rrt_params):
 
     def __init__(self, **kw):
         super().__init__()
-        _lib.check(_lib.load().rrt_params_default(C.byref(self)), "rrt_params_default")
+        _lib.check(_lib.load().rrt_params_default_v4(C.byref(self)), "rrt_params_default")
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError(k)
@@ -156,9 +157,14 @@ class Workspace:
         self.id, self.nbytes = i.value, int(nbytes)
 
     def stats(self):
+        """Of the last launch (synchronous): rows pooled over all its rounds, wavefronts still suspended after the last
+        round (finished in line), rounds enqueued / with work, rows of the fullest round, rows the pool holds at most."""
         rows, ovf = C.c_uint(0), C.c_uint(0)
         _lib.check(_lib.load().rrt_workspace_stats(self.id, C.byref(rows), C.byref(ovf)), "rrt_workspace_stats")
-        return {"rows_used": rows.value, "overflow_waves": ovf.value}
+        a, b, c, d = C.c_uint(0), C.c_uint(0), C.c_uint(0), C.c_uint(0)
+        _lib.check(_lib.load().rrt_workspace_rounds(self.id, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "rrt_workspace_rounds")
+        return {"rows_used": rows.value, "overflow_waves": ovf.value, "rounds_enqueued": a.value, "rounds_with_work": b.value,
+                "peak_rows": c.value, "pool_rows": d.value}
 
     def destroy(self):
         if getattr(self, "id", 0):
@@ -197,6 +203,15 @@ class TileOrder:
             out["perm"], out["cost"] = perm, cost
         return out
 
+    def set_seeding(self, on):
+        """on (default): a launch without history for its geometry takes its order from a coarse probe of the view."""
+        _lib.check(_lib.load().rrt_tile_order_set_seeding(self.id, 1 if on else 0), "rrt_tile_order_set_seeding")
+
+    def seeded_launches(self):
+        n = C.c_ulonglong(0)
+        _lib.check(_lib.load().rrt_tile_order_seeded(self.id, C.byref(n)), "rrt_tile_order_seeded")
+        return n.value
+
     def destroy(self):
         if getattr(self, "id", 0):
             _lib.load().rrt_tile_order_destroy(self.id)
@@ -207,6 +222,71 @@ class TileOrder:
             self.destroy()
         except Exception:
             pass
+
+
+class TileMap:
+    """Explicit tile -> shard assignment (cost-weighted instead of t mod n_shards).  shard_of_tile[t] for
+    every row tile t of `tile_rows` image rows; device-resident, tied to the current device."""
+
+    def __init__(self, height, tile_rows, n_shards, shard_of_tile):
+        m = np.ascontiguousarray(shard_of_tile, dtype=np.int32)
+        if m.shape != ((height + tile_rows - 1) // tile_rows,):
+            raise ValueError("shard_of_tile must have one entry per row tile")
+        i = C.c_int(0)
+        _lib.check(_lib.load().rrt_tile_map_create(height, tile_rows, n_shards, m.ctypes.data, C.byref(i)), "rrt_tile_map_create")
+        self.id, self.height, self.tile_rows, self.n_shards, self.shard_of_tile = i.value, height, tile_rows, n_shards, m
+
+    def shard_rows(self, shard):
+        r = C.c_int(0)
+        _lib.check(_lib.load().rrt_tile_map_shard_rows(self.id, shard, C.byref(r), None), "rrt_tile_map_shard_rows")
+        return r.value
+
+    def max_shard_rows(self):
+        r = C.c_int(0)
+        _lib.check(_lib.load().rrt_tile_map_shard_rows(self.id, 0, None, C.byref(r)), "rrt_tile_map_shard_rows")
+        return r.value
+
+    def destroy(self):
+        if getattr(self, "id", 0):
+            _lib.load().rrt_tile_map_destroy(self.id)
+            self.id = 0
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def probe_tile_costs(w, h, tile_rows, time, cam, effects, params=None, stream=None):
+    """Estimated cost of every row tile from the coarse march-only probe of the view (synchronous; float32 array)."""
+    n = (h + tile_rows - 1) // tile_rows
+    out = np.zeros(n, np.float32)
+    _lib.check(_lib.load().rrt_probe_tile_costs(w, h, tile_rows, float(time), C.byref(cam), C.byref(effects),
+                                                C.byref(params) if params is not None else None, out.ctypes.data, n,
+                                                _stream(stream)), "rrt_probe_tile_costs")
+    return out
+
+
+def balance_tiles(tile_cost, n_shards, max_tiles_per_shard=0):
+    """rrt_tile_map_balance: tiles dealt longest-first to the least loaded shard (deterministic host arithmetic)."""
+    c = np.ascontiguousarray(tile_cost, dtype=np.float32)
+    out = np.zeros(len(c), np.int32)
+    _lib.check(_lib.load().rrt_tile_map_balance(len(c), c.ctypes.data, n_shards, max_tiles_per_shard, out.ctypes.data),
+               "rrt_tile_map_balance")
+    return out
+
+
+def clock_probe_ghz(duration_us=20000, stream=None):
+    """The shader clock the chip holds right now (GHz): rrt_clock_probe on `stream` (default: a side stream, so that it
+    runs BESIDE whatever the current stream is busy with), synchronous."""
+    import torch
+    buf = torch.zeros(2, dtype=torch.int64, device="cuda")
+    st = stream if stream is not None else torch.cuda.Stream()
+    _lib.check(_lib.load().rrt_clock_probe(_ptr(buf), int(duration_us), _stream(st)), "rrt_clock_probe")
+    st.synchronize()
+    c = buf.cpu().numpy()
+    return float(c[0]) / max(float(c[1]), 1.0) * 0.1
 
 
 TABLE_FULL, TABLE_COARSE, TABLE_COARSEST = 0, 1, 2      # rrt.h: which noise call families a table serves
@@ -385,6 +465,19 @@ def assemble_tiles(d_frame, d_tiles, w, h, tile_rows, shard, n_shards, stream=No
 def assemble_all_tiles(d_frame, d_tiles_all, shard_stride_bytes, w, h, tile_rows, n_shards, stream=None):
     _lib.check(_lib.load().rrt_assemble_all_tiles(_ptr(d_frame), _ptr(d_tiles_all), shard_stride_bytes, w, h,
                                                   tile_rows, n_shards, _stream(stream)), "rrt_assemble_all_tiles")
+
+
+def launch_raymarch_tilemap(d_out_tiles, w, h, tile_map, shard, time, cam, skyboxTex, effects, params=None, stream=None):
+    _lib.check(_lib.load().rrt_launch_raymarch_tilemap(_ptr(d_out_tiles), w, h, tile_map.id if isinstance(tile_map, TileMap) else int(tile_map),
+                                                       shard, float(time), C.byref(cam), _sky_handle(skyboxTex), C.byref(effects),
+                                                       C.byref(params) if params is not None else None, _stream(stream)),
+               "rrt_launch_raymarch_tilemap")
+
+
+def assemble_all_tilemap(d_frame, d_tiles_all, shard_stride_bytes, w, h, tile_map, stream=None):
+    _lib.check(_lib.load().rrt_assemble_all_tilemap(_ptr(d_frame), _ptr(d_tiles_all), shard_stride_bytes, w, h,
+                                                    tile_map.id if isinstance(tile_map, TileMap) else int(tile_map),
+                                                    _stream(stream)), "rrt_assemble_all_tilemap")
 
 
 def launch_raymarch_debug(d_out, w, h, time, cam, skyboxTex, effects, params=None, stream=None, **outs):

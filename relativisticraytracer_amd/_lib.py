@@ -37,9 +37,10 @@ class rrt_effects(C.Structure):
 
 
 class rrt_params(C.Structure):
-    _fields_ = [("spin", C.c_float), ("max_steps", C.c_int32), ("volumetrics", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("spin", C.c_float), ("max_steps", C.c_int32), ("volumetrics", C.c_int32),
                 ("sky_frac_bits", C.c_int32), ("arith_mode", C.c_int32), ("workspace", C.c_int32),
-                ("path_policy", C.c_int32), ("noise_table", C.c_int32), ("tile_order", C.c_int32)]
+                ("path_policy", C.c_int32), ("noise_table", C.c_int32), ("tile_order", C.c_int32),
+                ("pool_rounds", C.c_int32)]
 
 
 class rrt_debug_outputs(C.Structure):
@@ -56,7 +57,7 @@ SYMBOLS = [
     ("rrt_status_string", C.c_char_p, [_i]),
     ("rrt_last_hip_error", C.c_char_p, []),
     ("rrt_device_count", _i, [C.POINTER(_i)]),
-    ("rrt_params_default", _i, [_prm]),
+    ("rrt_params_default_v4", _i, [_prm]),
     ("rrt_effects_default", _i, [_fx]),
     ("rrt_sky_create", _i, [_vp, _i, _i, C.POINTER(_ull)]),
     ("rrt_sky_create_from_device", _i, [_vp, _i, _i, C.POINTER(_ull)]),
@@ -65,6 +66,17 @@ SYMBOLS = [
     ("rrt_workspace_destroy", _i, [_i]),
     ("rrt_tile_order_create", _i, [C.POINTER(_i)]),
     ("rrt_tile_order_destroy", _i, [_i]),
+    ("rrt_tile_order_set_seeding", _i, [_i, _i]),
+    ("rrt_tile_order_seeded", _i, [_i, C.POINTER(_ull)]),
+    ("rrt_tile_map_create", _i, [_i, _i, _i, _vp, C.POINTER(_i)]),
+    ("rrt_tile_map_destroy", _i, [_i]),
+    ("rrt_tile_map_shard_rows", _i, [_i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    ("rrt_tile_map_balance", _i, [_i, _vp, _i, _i, _vp]),
+    ("rrt_probe_tile_costs", _i, [_i, _i, _i, _f, _cam, _fx, _prm, _vp, _i, _vp]),
+    ("rrt_launch_raymarch_tilemap", _i, [_vp, _i, _i, _i, _i, _f, _cam, _ull, _fx, _prm, _vp]),
+    ("rrt_assemble_all_tilemap", _i, [_vp, _vp, C.c_size_t, _i, _i, _i, _vp]),
+    ("rrt_clock_probe", _i, [_vp, C.c_uint, _vp]),
+    ("rrt_workspace_rounds", _i, [_i, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     ("rrt_tile_order_info", _i, [_i, C.POINTER(_ull), C.POINTER(_ull), C.POINTER(C.c_uint), _vp, _vp, C.c_uint]),
     ("rrt_noise_table_create", _i, [_f, C.POINTER(_i)]),
     ("rrt_noise_table_destroy", _i, [_i]),

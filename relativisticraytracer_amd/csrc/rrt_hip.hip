@@ -20,6 +20,7 @@
 #include <hipcub/hipcub.hpp>        /* DeviceRadixSort for rrt_tile_order */
 
 #include <atomic>
+#include <memory>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +28,8 @@
 #include <mutex>
 #include <new>
 #include <unordered_map>
+#include <vector>
+#include <algorithm>
 
 #include "../../include/rrt.h"
 #include "rrt_device.h"
@@ -56,6 +59,10 @@ int hip_fail(hipError_t e, const char* what) {
  * (the one-process N-GPU driver and the process-global launch defaults make that mistake easy).
  * rrt_debug_fake_device() lets a CPU-only test drive those checks. */
 std::atomic<int> g_fake_device{-1};
+bool test_hooks_enabled() {       /* decided once, from the environment the process was started with */
+    static const bool on = [] { const char* e = getenv("RRT_ENABLE_TEST_HOOKS"); return e && e[0] == '1'; }();
+    return on;
+}
 int current_device() {
     const int fake = g_fake_device.load(std::memory_order_relaxed);
     if (fake >= 0) return fake;
@@ -105,8 +112,22 @@ rrt_sky_t sky_register(const SkyObject& s) {
  * walks a heavy wave's samples.  Block layout: kBlockRows x six SoA float[64] planes (p.xyz, vel.xyz in;
  * ex, ey, ez, transmittance out in planes 0-3), then a trailer {lane mask of each row; in the first
  * block of a run: start and length of the wave's next run}.  Unused rows keep a zero mask. */
-struct DeferCounters { unsigned next_block, overflow_waves, pad0, pad1; };
-struct WaveHdr { unsigned first_block, n_runs, state, pad; };     /* state: 1 marched, 2 marched until the pool ran out */
+/* Round 4: the pool is reused in ROUNDS.  A round = march until the pool is full (waves the pool ran out under are
+ * SUSPENDED: pre-step state and the radiance composited so far are saved per ray) -> evaluate the pooled rows -> composite
+ * them; the next round resumes the suspended waves into the emptied pool.  Any pool serves any view; the in-line fall-back
+ * only finishes what is still suspended after the last round the host enqueued. */
+struct DeferCounters {
+    unsigned next_block, overflow_waves;      /* of the current round */
+    unsigned last_overflow;                   /* waves suspended when this round started (0: nothing left to do) */
+    unsigned rounds_run, rounds_with_work;    /* rounds enqueued so far / rounds whose march had something to do */
+    unsigned peak_blocks;                     /* most blocks any round used */
+    unsigned suspended_left;                  /* waves still suspended after the last round: finished in line */
+    unsigned pad;
+    unsigned long long total_blocks;
+};
+/* state: 0 untouched, 1 marched to its end this round, 2 suspended (the pool ran out under it), 3 shaded.
+ * flags bit 0: the rays' radiance so far is saved in `finals` (planes 7-10). */
+struct WaveHdr { unsigned first_block, n_runs, state, flags; };
 constexpr unsigned kMaxRun = 32;
 constexpr unsigned kMaxRunsWalked = 4096;                          /* runs of one wave that pass 3 will walk */
 constexpr unsigned kBlockRows = 8;
@@ -115,7 +136,10 @@ constexpr unsigned kBlockTrailer = kBlockRows * kRowData;         /* masks[kBloc
 constexpr unsigned kBlockBytes = kBlockTrailer + kBlockRows * 8 + 64;
 constexpr unsigned kNoBlock = 0xffffffffu;
 
-struct WorkspaceObject { uint8_t* d_base; size_t bytes; int device; };
+struct WorkspaceObject {
+    uint8_t* d_base; size_t bytes; int device;
+    DeferCounters* h_stats;      /* pinned host copy of the counters its last launch left (asynchronous, behind that launch) */
+};
 std::mutex g_ws_mu;
 std::unordered_map<int, WorkspaceObject> g_ws;
 int g_ws_next = 1;
@@ -286,6 +310,7 @@ struct RowMap {        /* local row -> image row, and where its pixels go */
     int tile_rows;     /* R                                                           */
     int shard;         /* s                                                           */
     int n_shards;      /* G: local tile k is image tile s + k*G                       */
+    const int* tile_of_local;   /* rrt_tile_map: local tile k is image tile tile_of_local[k] (increasing); NULL: the rule above */
 };
 
 struct FrameArgs {
@@ -318,6 +343,24 @@ struct FrameArgs {
     int tile_order_id;      /* host side only: rrt_params.tile_order */
 };
 
+/* ------------------------------------------------------------------ explicit tile -> shard maps (rrt_tile_map)
+ * SURVEY.md 8e's "cost-model-weighted assignment": instead of tile t -> shard t mod G, any assignment.  The object keeps a
+ * device image of the lists the kernels index (a shard's tiles in increasing t; every tile's shard and place), tied to
+ * the device it was created on. */
+struct TileMapObject {
+    int height, tile_rows, n_shards, n_tiles, device;
+    std::vector<int> shard_of_tile, offset, rows;    /* offset[s]: where shard s's tiles start in tile_of_local */
+    int* d_img = nullptr;
+};
+std::mutex g_tm_mu;
+std::unordered_map<int, std::shared_ptr<TileMapObject>> g_tm;
+int g_tm_next = 1;
+std::shared_ptr<TileMapObject> tile_map_lookup(int id) {
+    std::lock_guard<std::mutex> lk(g_tm_mu);
+    auto it = g_tm.find(id);
+    return it == g_tm.end() ? nullptr : it->second;
+}
+
 /* ------------------------------------------------------------------ cost-ordered dispatch (rrt_tile_order)
  * Workgroups are dispatched in blockIdx order and a wave tile's cost is only known once it has been rendered, so the
  * static order (row blocks from the middle outwards) is right for the reference's default view and wrong wherever the
@@ -339,11 +382,25 @@ struct TileOrderObject {
     unsigned grid_x, grid_y;
     int width, height; RowMap rows;
     hipEvent_t chained;      /* after the last sort */
-    unsigned long long launches, ordered;
+    unsigned long long launches, ordered, seeded;
+    bool no_seed;            /* rrt_tile_order_set_seeding(id, 0): a geometry without history renders in the static order */
+    bool dead;               /* destroyed (a launch that was waiting for `mu` must not touch the buffers) */
+    std::mutex mu;           /* launches through one object are serialised on the host as well */
 };
+bool same_row_map(const RowMap& a, const RowMap& b) {
+    return a.n_local_rows == b.n_local_rows && a.y_base == b.y_base && a.tile_rows == b.tile_rows && a.shard == b.shard &&
+           a.n_shards == b.n_shards && a.tile_of_local == b.tile_of_local;
+}
+/* the registry lock only covers the lookup; an object is pinned by its shared_ptr and serialised by its own mutex, so
+ * threads driving different objects (different GPUs) never wait for each other */
 std::mutex g_to_mu;
-std::unordered_map<int, TileOrderObject> g_to;
+std::unordered_map<int, std::shared_ptr<TileOrderObject>> g_to;
 int g_to_next = 1;
+std::shared_ptr<TileOrderObject> tile_order_lookup(int id) {
+    std::lock_guard<std::mutex> lk(g_to_mu);
+    auto it = g_to.find(id);
+    return it == g_to.end() ? nullptr : it->second;
+}
 
 __global__ __launch_bounds__(256) void fill_iota(unsigned* v, unsigned n) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
@@ -355,7 +412,7 @@ __device__ __forceinline__ bool map_row(const RowMap& m, int height, int lr, int
     if (lr >= m.n_local_rows) return false;
     int k = lr / m.tile_rows;
     int rr = lr - k * m.tile_rows;
-    int t = m.shard + k * m.n_shards;
+    int t = m.tile_of_local ? m.tile_of_local[k] : m.shard + k * m.n_shards;
     int ty0 = m.y_base + t * m.tile_rows;
     y = ty0 + rr;
     if (y >= height) return false;
@@ -678,8 +735,17 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     }
     return v;
 }
-__device__ __forceinline__ unsigned wave_index() {
-    return (blockIdx.y * gridDim.x + blockIdx.x) * (unsigned)kWGWaves + (threadIdx.x >> 6);
+/* where a wavefront keeps its bookkeeping in the three-pass workspace: by the wave TILE it renders, so that the three passes
+ * (and the rounds) find the same slot whatever order they are dispatched in */
+__device__ __forceinline__ unsigned wave_slot(const FrameArgs& a) {
+    return wave_tile(a) * (unsigned)kWGWaves + (threadIdx.x >> 6);
+}
+/* add this wave's lifetime (clocks / 16) to its tile's cost (every lane stores the same word) */
+__device__ __forceinline__ void add_tile_cost(const FrameArgs& a, unsigned long long t_start) {
+    const unsigned long long dt = (__builtin_readcyclecounter() - t_start) >> 4;
+    const unsigned t = wave_tile(a);
+    const unsigned long long sum = (unsigned long long)a.tile_cost[t] + dt;
+    a.tile_cost[t] = sum > kTileCostMax ? kTileCostMax : (unsigned)sum;
 }
 
 /* Single-kernel path: one ray per lane, media sampled in line (reference raymarch_kernel,
@@ -718,20 +784,37 @@ void raymarch_pixels(const FrameArgs a) {
 
 /* ---- three-pass path, pass 1: geodesics only; sample points of in-medium steps go to the pool ---- */
 /* amdgpu_num_sgpr(80): gfx950 admits 8 waves per SIMD only up to 80 SGPRs (7 for 82-96); this loop needs
- * the occupancy (measured: 4 waves/SIMD is 15 % slower than 8). */
-template <bool SPIN, bool FAST>
+ * the occupancy (measured: 4 waves/SIMD is 15 % slower than 8).
+ * RESUME (rounds after the first): only wavefronts the pool ran out under (state 2) do anything -- their suspended rays
+ * carry on from the saved pre-step state; rays of the same wave that had already ended stay as they are. */
+template <bool SPIN, bool FAST, bool RESUME>
 __global__ __launch_bounds__(kWGThreads, 8) __attribute__((amdgpu_num_sgpr(80))) void march_defer(const FrameArgs a) {
+    if (RESUME && a.ctr->last_overflow == 0u) return;            /* nothing was suspended: the whole grid leaves at once */
+    const unsigned long long t_start = a.tile_cost ? __builtin_readcyclecounter() : 0ull;
     int x = 0, y = 0, out_row = 0;
     const bool valid = lane_pixel(a, x, y, out_row);
     if (!__any(valid)) return;
-    /* lanes without a pixel stay alive (all 64 lanes take part in the wave-level bookkeeping below);
-     * they march nothing: their loop count starts at max_steps */
+    /* lanes without a pixel stay alive (all 64 lanes take part in the wave-level bookkeeping below); they march nothing */
     const int lane = threadIdx.x & 63;
+    const unsigned wid = wave_slot(a);
+    const size_t li = (size_t)wid * 64 + lane;
     v3 p = mk(1000.f, 0.f, 0.f), vel = mk(0.f, 0.f, 0.f);
-    if (valid) { float uvx, uvy; primary_ray(a, x, y, uvx, uvy, p, vel); }
-
     bool hit = false;
-    int i = valid ? 0 : a.max_steps;
+    bool active = valid;                                          /* this lane marches in this round */
+    int i = 0;
+    if (RESUME) {
+        if (a.hdr[wid].state != 2u) return;                       /* wave-uniform: marched to its end, or shaded already */
+        const unsigned code = reinterpret_cast<const unsigned*>(a.finals)[3 * a.n_lanes + li];
+        vel = mk(a.finals[li], a.finals[a.n_lanes + li], a.finals[2 * a.n_lanes + li]);
+        p = mk(a.finals[4 * a.n_lanes + li], a.finals[5 * a.n_lanes + li], a.finals[6 * a.n_lanes + li]);
+        hit = (code >> 31) != 0;
+        i = (int)(code & 0x3fffffffu);
+        active = valid && (code & 0x40000000u) != 0;
+    } else if (valid) {
+        float uvx, uvy;
+        primary_ray(a, x, y, uvx, uvy, p, vel);
+    }
+
     /* wave-level bookkeeping; identical in every lane that is still marching */
     unsigned first_block = kNoBlock, n_runs = 0;
     unsigned run_start = kNoBlock, run_len = 0, run_blk = 0;      /* current run; block run_start + run_blk in use */
@@ -739,8 +822,9 @@ __global__ __launch_bounds__(kWGThreads, 8) __attribute__((amdgpu_num_sgpr(80)))
     bool overflow = false;                                        /* this lane stopped because the pool is full */
 
     constexpr bool LEAN = !FAST && RRT_MARCH_V2;               /* round 3's step (march_inline has the notes) */
-    float y_seed = 0.0f, h_seed = 0.0f, hc_prev = 0.0f;
-    for (; i < a.max_steps; ++i) {
+    float y_seed = 0.0f, h_seed = 0.0f, hc_prev = 0.0f;        /* a resumed ray starts without seeds: its first root takes the
+                                                                * v_rsq fall-back, which is the same correctly rounded root */
+    for (; active && i < a.max_steps; ++i) {
         const v3 rel_p = p;
         float r2, r, yv, hv = 0.0f;
         bool vacuum = false;
@@ -770,7 +854,7 @@ __global__ __launch_bounds__(kWGThreads, 8) __attribute__((amdgpu_num_sgpr(80)))
          * [ISCO, DISK_OUT] (densities.h:21-22, :70-71); only those steps need a sample.  rc comes from
          * sqrt_rsq, which equals sqrtf bit for bit on [1, 2^64) (self-checked); rc2 < 1 is outside anyway.
          * The row is reserved BEFORE the step is taken: if the pool is full the lane stops here with its
-         * pre-step state intact, and pass 3 resumes it with the media sampled in line. */
+         * pre-step state intact, and the next round (or, after the last one, pass 3 in line) resumes it. */
         unsigned long long need_mask = 0ull;
         bool need = false;
         float* row_f = nullptr;
@@ -847,7 +931,6 @@ __global__ __launch_bounds__(kWGThreads, 8) __attribute__((amdgpu_num_sgpr(80)))
     }
 
     /* wave-level epilogue: all 64 lanes are here */
-    const unsigned wid = wave_index();
     const bool any_overflow = __any(overflow);
     /* lanes that left the loop early hold stale copies of the bookkeeping: the lane that ran longest has
      * the final run count, and any lane that saw the first allocation has first_block */
@@ -855,7 +938,6 @@ __global__ __launch_bounds__(kWGThreads, 8) __attribute__((amdgpu_num_sgpr(80)))
     first_block = ~wave_max_u32(~first_block);
     /* terminal (or, on overflow, resumable) state of every ray; pass 3 shades all pixels -- keeping the sky
      * and post-FX code with its scalar operands out of this kernel keeps it at 8 waves per SIMD */
-    const size_t li = (size_t)wid * 64 + lane;
     a.finals[li] = vel.x;
     a.finals[a.n_lanes + li] = vel.y;
     a.finals[2 * a.n_lanes + li] = vel.z;
@@ -868,6 +950,19 @@ __global__ __launch_bounds__(kWGThreads, 8) __attribute__((amdgpu_num_sgpr(80)))
         a.hdr[wid].first_block = first_block; a.hdr[wid].n_runs = n_runs; a.hdr[wid].state = any_overflow ? 2u : 1u;
         if (any_overflow) atomicAdd(&a.ctr->overflow_waves, 1u);
     }
+    if (a.tile_cost) add_tile_cost(a, t_start);
+}
+
+/* between two rounds (one thread): close the round's statistics and empty the pool */
+__global__ void pool_next_round(DeferCounters* c, unsigned capacity, int last) {
+    const unsigned used = c->next_block < capacity ? c->next_block : capacity;
+    if (used > c->peak_blocks) c->peak_blocks = used;
+    c->total_blocks += used;
+    if (c->rounds_run == 0u || c->last_overflow != 0u) ++c->rounds_with_work;
+    ++c->rounds_run;
+    c->last_overflow = c->overflow_waves;
+    if (last) c->suspended_left = c->overflow_waves;
+    c->next_block = 0u; c->overflow_waves = 0u;
 }
 
 /* ---- pass 2: densities + emission of every pooled sample row, grid-stride over the pool ---- */
@@ -901,22 +996,24 @@ __global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
     }
 }
 
-/* ---- pass 3: composite each ray's samples in march order, resume rays the pool ran out under, shade ---- */
-template <bool SPIN, bool FAST, bool LUT>
+/* ---- pass 3: composite each ray's samples in march order; shade the rays of wavefronts that have reached their end;
+ *      LAST (the last round the host enqueued): rays still suspended are finished with the media sampled in line ---- */
+template <bool SPIN, bool FAST, bool LUT, bool LAST>
 __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArgs a) {
+    if (a.ctr->rounds_run != 0u && a.ctr->last_overflow == 0u) return;      /* a later round with nothing left: all leave */
+    const unsigned long long t_start = a.tile_cost ? __builtin_readcyclecounter() : 0ull;
     int x, y, out_row;
     if (!lane_pixel(a, x, y, out_row)) return;
     const int lane = threadIdx.x & 63;
-    const unsigned wid = wave_index();
+    const unsigned wid = wave_slot(a);
     const unsigned state = a.hdr[wid].state;
-    float uvx, uvy;
-    v3 p, vel;
-    primary_ray(a, x, y, uvx, uvy, p, vel);
+    if (state != 1u && state != 2u) return;                        /* shaded in an earlier round */
     const size_t li = (size_t)wid * 64 + lane;
-    vel = mk(a.finals[li], a.finals[a.n_lanes + li], a.finals[2 * a.n_lanes + li]);
-    const unsigned code = reinterpret_cast<const unsigned*>(a.finals)[3 * a.n_lanes + li];
-    bool hit = (code >> 31) != 0;
     Radiance acc = {0.f, 0.f, 0.f, 1.0f};
+    if (a.hdr[wid].flags & 1u) {                                   /* the radiance composited in earlier rounds */
+        acc.r = a.finals[7 * a.n_lanes + li]; acc.g = a.finals[8 * a.n_lanes + li];
+        acc.b = a.finals[9 * a.n_lanes + li]; acc.t = a.finals[10 * a.n_lanes + li];
+    }
     unsigned run_start = a.hdr[wid].first_block, run_len = 1;
     const unsigned n_runs = min(a.hdr[wid].n_runs, kMaxRunsWalked);
     for (unsigned rn = 0; rn < n_runs; ++rn) {
@@ -955,15 +1052,128 @@ __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArg
         }
         run_start = next_start; run_len = next_len;
     }
+    const int leader = __ffsll((long long)__ballot(1)) - 1;
+    if (!LAST && state == 2u) {
+        /* the wave is suspended: keep what has been composited; the next round's march resumes its rays */
+        a.finals[7 * a.n_lanes + li] = acc.r; a.finals[8 * a.n_lanes + li] = acc.g;
+        a.finals[9 * a.n_lanes + li] = acc.b; a.finals[10 * a.n_lanes + li] = acc.t;
+        if (lane == leader) a.hdr[wid].flags = 1u;
+        if (a.tile_cost) add_tile_cost(a, t_start);
+        return;
+    }
+    float uvx, uvy;
+    v3 p, vel;
+    primary_ray(a, x, y, uvx, uvy, p, vel);
+    vel = mk(a.finals[li], a.finals[a.n_lanes + li], a.finals[2 * a.n_lanes + li]);
+    const unsigned code = reinterpret_cast<const unsigned*>(a.finals)[3 * a.n_lanes + li];
+    bool hit = (code >> 31) != 0;
     int steps = (int)(code & 0x3fffffffu);
-    if (state == 2 && (code & 0x40000000u)) {
-        /* the pool ran out under this ray at step `steps`: carry on from its saved pre-step state with the
-         * media sampled in line -- the samples composited above come first, exactly as in the single kernel */
+    if (LAST && state == 2u && (code & 0x40000000u)) {
+        /* the pool ran out under this ray at step `steps` and no round is left: carry on from its saved pre-step state
+         * with the media sampled in line -- the samples composited above come first, exactly as in the single kernel */
         p = mk(a.finals[4 * a.n_lanes + li], a.finals[5 * a.n_lanes + li], a.finals[6 * a.n_lanes + li]);
         march_inline<SPIN, LUT ? 2 : 1, FAST>(a, p, vel, acc, hit, steps, nullptr);
     }
     if (hit) acc.t = 0.0f;                                         /* raymarcher.cu:49 */
     shade_and_store<false>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, steps);
+    if (lane == leader) a.hdr[wid].state = 3u;
+    if (a.tile_cost) add_tile_cost(a, t_start);
+}
+
+/* ---- coarse cost probe (round 4): one march-only ray per cell of stride_x x stride_y pixels of the launch's row map.
+ * No media evaluation, no shading: the geodesic with the march's own step rule, counting steps and the steps that would
+ * need an accretion / a dust sample.  cost = w_step steps + w_acc n_acc + w_dust n_dust, in the unit of the measured tile
+ * costs (wave clocks / 16: a 1000-step wave at full occupancy ~ 1.7e5), so that the same radix sort orders both.  Used
+ * (i) to dispatch the FIRST frame of a geometry longest-first (rrt_tile_order has no history yet) and (ii) on the host, to
+ * weigh row tiles before they are dealt to the GPUs (rrt_probe_tile_costs -> rrt_tile_map_balance).  The weights are a
+ * least-squares fit of this model to measured wave-tile costs of six 4K views (tools/probe_fit.py,
+ * profiles/r04_probe_cost_fit.txt). */
+struct ProbeArgs {
+    unsigned* cell_cost;       /* cells_y x cells_x */
+    int cells_x, cells_y, stride_x, stride_y;
+    float w_step, w_acc, w_dust;
+};
+#ifndef RRT_PROBE_W_STEP
+#define RRT_PROBE_W_STEP 170.0f
+#define RRT_PROBE_W_ACC 330.0f
+#define RRT_PROBE_W_DUST 1200.0f
+#endif
+constexpr int kProbeStride = 16;
+
+template <bool SPIN>
+__global__ __launch_bounds__(64) void probe_costs(const FrameArgs a, const ProbeArgs q) {
+    const int lane = threadIdx.x & 63;
+    const int cx = blockIdx.x * 8 + (lane & 7), cy = blockIdx.y * 8 + (lane >> 3);
+    if (cx >= q.cells_x || cy >= q.cells_y) return;
+    /* the cell's representative pixel: its centre, in the LOCAL rows of the launch (a shard probes its own tiles only) */
+    int lr = cy * q.stride_y + q.stride_y / 2, y = 0, out_row = 0;
+    if (lr >= a.rows.n_local_rows) lr = a.rows.n_local_rows - 1;
+    if (!map_row(a.rows, a.height, lr, y, out_row) && !map_row(a.rows, a.height, cy * q.stride_y, y, out_row)) {
+        q.cell_cost[cy * q.cells_x + cx] = 0u;
+        return;
+    }
+    const int xc = cx * q.stride_x + q.stride_x / 2;
+    const int x = xc < a.width ? xc : a.width - 1;
+    float uvx, uvy;
+    v3 p, vel;
+    primary_ray(a, x, y, uvx, uvy, p, vel);
+    int steps = a.max_steps;
+    unsigned n_acc = 0, n_dust = 0;
+    float ys = 0.0f, hs = 0.0f, hcp = 0.0f;
+    for (int k = 0; k < a.max_steps; ++k) {
+        const v3 rel_p = p;
+        const float r2 = dot(rel_p, rel_p);
+        float r, yv, hy;
+        const bool rejected = sqrt_seeded_yh<1>(r2, ys, hs, r, yv, hy);
+        const unsigned long long rej_mask = __builtin_amdgcn_ballot_w64(rejected);
+        const bool vacuum = (rej_mask | __builtin_amdgcn_ballot_w64(!(r >= kVacuumR))) == 0ull;
+        if (!vacuum && rej_mask != 0ull) {
+            bool small;
+            if (rejected) radius_fallback(r2, r, yv, hy, small);
+        }
+        if (r < kEventHorizon * 1.01f) { steps = k; break; }
+        if (vacuum) {
+            integrate_rk4_lean<SPIN, true>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, yv, hy, ys, hs, hcp);
+        } else {
+            const bool near_bh = r < 18.0f;
+            const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
+            const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
+            float h, hh, h6;
+            zone_step(near_bh, in_disk, h, hh, h6);
+            integrate_rk4_lean<SPIN, false>(p, vel, h, hh, h6, a.drag_c, r2, r, yv, hy, ys, hs, hcp);
+            if (in_disk || in_cloud) {
+                const float rc2 = rel_p.x * rel_p.x + rel_p.z * rel_p.z;
+                if (rc2 >= kIsco * kIsco && rc2 <= kDiskOut * kDiskOut) {
+                    /* the slab early-out of disk_point(): y^2 rc > 135 ends both densities twelve instructions in */
+                    if (rel_p.y * rel_p.y * rel_p.y * rel_p.y * rc2 <= 135.0f * 135.0f) { n_acc += in_disk; n_dust += in_cloud; }
+                }
+            }
+        }
+        if (r > 250.0f && dot(rel_p, vel) > 0.0f) { steps = k + 1; break; }
+    }
+    const float c = q.w_step * (float)steps + q.w_acc * (float)n_acc + q.w_dust * (float)n_dust;
+    q.cell_cost[cy * q.cells_x + cx] = c >= (float)kTileCostMax ? kTileCostMax : (unsigned)c;
+}
+/* every wave tile (tiles_x x tiles_y of kWGPixX x kWGPixY pixels) takes the cost of the probe cell it lies in */
+__global__ __launch_bounds__(256) void probe_to_tiles(unsigned* tile_cost, unsigned tiles_x, unsigned tiles_y, ProbeArgs q) {
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= tiles_x * tiles_y) return;
+    const unsigned rb = t / tiles_x, col = t - rb * tiles_x;
+    int cx = (int)(col * kWGPixX) / q.stride_x, cy = (int)(rb * kWGPixY) / q.stride_y;
+    cx = cx < q.cells_x ? cx : q.cells_x - 1; cy = cy < q.cells_y ? cy : q.cells_y - 1;
+    tile_cost[t] = q.cell_cost[cy * q.cells_x + cx];
+}
+
+/* one wavefront sleeps for `ticks` of the 100 MHz counter and reports both counters' deltas (rrt_clock_probe) */
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, unsigned long long ticks) {
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r1 = r0;
+    for (unsigned it = 0; it < (1u << 24) && r1 - r0 < ticks; ++it) {       /* bounded: ~1.3 us per turn */
+        __builtin_amdgcn_s_sleep(127);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
 }
 
 /* scatter one shard's tile buffer into the full bottom-up frame */
@@ -989,6 +1199,19 @@ __global__ __launch_bounds__(256) void assemble_all_kernel(uchar4* frame, const 
         const int rows_k = min(tile_rows, height - t * tile_rows);
         const size_t src_row = (size_t)k * tile_rows + (rows_k - 1 - rr);
         frame[(size_t)(height - 1 - y) * width + x] = tiles[shard * shard_stride + src_row * width + x];
+    }
+}
+
+/* all shards of an explicit tile map (rrt_tile_map) in one launch */
+__global__ __launch_bounds__(256) void assemble_map_kernel(uchar4* frame, const uchar4* tiles, size_t shard_stride, int width,
+                                                          int height, int tile_rows, const int* shard_of_tile, const int* k_of_tile) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= width) return;
+    for (int y = blockIdx.y; y < height; y += gridDim.y) {
+        const int t = y / tile_rows, rr = y - t * tile_rows;
+        const int rows_k = min(tile_rows, height - t * tile_rows);
+        const size_t src_row = (size_t)k_of_tile[t] * tile_rows + (rows_k - 1 - rr);
+        frame[(size_t)(height - 1 - y) * width + x] = tiles[shard_of_tile[t] * shard_stride + src_row * width + x];
     }
 }
 
@@ -1356,23 +1579,41 @@ __global__ void k_selfcheck_div_const(uint32_t lo, uint32_t hi, unsigned long lo
 }
 
 /* ------------------------------------------------------------------ host helpers */
+/* an rrt_params built against another header is refused before any field of it is believed */
+int check_params_abi(const rrt_params* prm) {
+    if (prm && prm->struct_size != (uint32_t)sizeof(rrt_params)) {
+        snprintf(g_hip_err, sizeof(g_hip_err), "rrt_params.struct_size %u, this library's is %zu (ABI %d): recompile against include/rrt.h",
+                 prm->struct_size, sizeof(rrt_params), RRT_ABI_VERSION);
+        return RRT_ERR_ABI_MISMATCH;
+    }
+    return RRT_OK;
+}
+int check_params_values(const rrt_params* prm) {
+    if (prm->max_steps < 0 || prm->sky_frac_bits < 0 || prm->sky_frac_bits > 16) return RRT_ERR_INVALID_ARGUMENT;
+    if (!(prm->spin == prm->spin)) return RRT_ERR_INVALID_ARGUMENT;
+    if (prm->arith_mode != RRT_ARITH_STRICT && prm->arith_mode != RRT_ARITH_FAST) return RRT_ERR_INVALID_ARGUMENT;
+    if (prm->workspace < 0) return RRT_ERR_INVALID_ARGUMENT;
+    if (prm->path_policy < RRT_PATH_AUTO || prm->path_policy > RRT_PATH_THREE_PASS) return RRT_ERR_INVALID_ARGUMENT;
+    if (prm->noise_table < 0 || prm->tile_order < 0) return RRT_ERR_INVALID_ARGUMENT;
+    if (prm->pool_rounds < 0 || prm->pool_rounds > 64) return RRT_ERR_INVALID_ARGUMENT;
+    return RRT_OK;
+}
 int check_common(const void* out, int width, int height, const rrt_camera* cam, const rrt_effects* fx,
                  const rrt_params* prm) {
     if (!out || !cam || !fx || width <= 0 || height <= 0) return RRT_ERR_INVALID_ARGUMENT;
     if ((long long)width * height > (1ll << 31) - 1) return RRT_ERR_INVALID_ARGUMENT;
     if (height > kMaxGridY * kWGPixY) return RRT_ERR_INVALID_ARGUMENT;             /* 524 280 rows */
     if (prm) {
-        if (prm->max_steps < 0 || prm->sky_frac_bits < 0 || prm->sky_frac_bits > 16) return RRT_ERR_INVALID_ARGUMENT;
-        if (!(prm->spin == prm->spin)) return RRT_ERR_INVALID_ARGUMENT;
-        if (prm->arith_mode != RRT_ARITH_STRICT && prm->arith_mode != RRT_ARITH_FAST) return RRT_ERR_INVALID_ARGUMENT;
-        if (prm->workspace < 0) return RRT_ERR_INVALID_ARGUMENT;
-        if (prm->path_policy < RRT_PATH_AUTO || prm->path_policy > RRT_PATH_THREE_PASS) return RRT_ERR_INVALID_ARGUMENT;
-        if (prm->noise_table < 0 || prm->tile_order < 0) return RRT_ERR_INVALID_ARGUMENT;
+        const int rc = check_params_abi(prm);
+        if (rc != RRT_OK) return rc;
+        return check_params_values(prm);
     }
     return RRT_OK;
 }
 
-int fill_args(FrameArgs& a, int& media, bool& fast, int& workspace, int& policy, void* out, int width, int height, float time, const rrt_camera* cam,
+struct LaunchOpts { int media; bool fast; int workspace, policy, pool_rounds; };
+
+int fill_args(FrameArgs& a, LaunchOpts& o, void* out, int width, int height, float time, const rrt_camera* cam,
               rrt_sky_t sky, const rrt_effects* fx, const rrt_params* prm_in) {
     rrt_params prm;
     if (prm_in) prm = *prm_in; else rrt_params_default(&prm);
@@ -1392,7 +1633,11 @@ int fill_args(FrameArgs& a, int& media, bool& fast, int& workspace, int& policy,
     a.max_steps = prm.max_steps;
     memset(&a.dbg, 0, sizeof(a.dbg));
     a.tile_perm = nullptr; a.tile_cost = nullptr; a.tile_order_id = prm.tile_order;
-    media = prm.volumetrics != 0 ? 1 : 0;
+    if (prm.tile_order != 0) {                      /* whatever path the launch takes: a stale or foreign id is an error */
+        const std::shared_ptr<TileOrderObject> to = tile_order_lookup(prm.tile_order);
+        if (!to || !on_current_device(to->device)) return RRT_ERR_BAD_HANDLE;
+    }
+    o.media = prm.volumetrics != 0 ? 1 : 0;
     memset(&a.lut_acc, 0, sizeof(a.lut_acc)); memset(&a.lut_dust, 0, sizeof(a.lut_dust));
     if (prm.noise_table != 0) {
         NoiseTableObject nt;
@@ -1404,15 +1649,16 @@ int fill_args(FrameArgs& a, int& media, bool& fast, int& workspace, int& policy,
         }
         if (!on_current_device(nt.device)) return RRT_ERR_BAD_HANDLE;
         /* the boxes were sized for t0 <= time <= t1; any other time runs the arithmetic kernels (same bytes) */
-        if (media && time >= nt.t0 && time <= nt.t1) {
-            media = 2;
+        if (o.media && time >= nt.t0 && time <= nt.t1) {
+            o.media = 2;
             a.lut_acc = make_lut(nt.d_cells, nt.acc, nt.acc_families);
             a.lut_dust = make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust, nt.dust_families);
         }
     }
-    fast = prm.arith_mode == RRT_ARITH_FAST;
-    workspace = prm.workspace;
-    policy = prm.path_policy;
+    o.fast = prm.arith_mode == RRT_ARITH_FAST;
+    o.workspace = prm.workspace;
+    o.policy = prm.path_policy;
+    o.pool_rounds = prm.pool_rounds;
     a.ctr = nullptr; a.hdr = nullptr; a.finals = nullptr; a.n_lanes = 0; a.sample_blocks = nullptr; a.block_capacity = 0;
     return RRT_OK;
 }
@@ -1423,10 +1669,28 @@ int fill_args(FrameArgs& a, int& media, bool& fast, int& workspace, int& policy,
  * that.  Launches with more steps take the single kernel (same bytes). */
 constexpr long long kThreePassMaxSteps = (long long)(kMaxRunsWalked - 8) * kMaxRun * kBlockRows;   /* ~1.05 M */
 static_assert(kThreePassMaxSteps < (1ll << 30), "step count must fit beside the two flag bits");
+constexpr int kFinalPlanes = 11;      /* per ray: vel xyz, code, pos xyz, radiance rgbt */
+constexpr int kMaxPoolRounds = 64;
+
+/* How many rounds to enqueue (rrt_params.pool_rounds == 0).  The host cannot ask the device without stalling the
+ * stream, so it reads the statistics the workspace's PREVIOUS launch left in pinned host memory (an asynchronous copy
+ * behind its last kernel; possibly a frame stale, which is all an animation needs): as many rounds as that launch had
+ * work for, one more if its fullest round used over half the pool, twice as many if rays were still suspended at its
+ * end.  An idle round costs three near-empty launches (every wave leaves on one scalar load). */
+int auto_pool_rounds(const WorkspaceObject& ws, unsigned capacity) {
+    if (!ws.h_stats) return 2;
+    const volatile DeferCounters* h = ws.h_stats;
+    const unsigned run = h->rounds_run, work = h->rounds_with_work, left = h->suspended_left, peak = h->peak_blocks;
+    if (run == 0u) return 2;                                    /* no history */
+    int r = (int)(work > 0u ? work : 1u);
+    if (left != 0u) r *= 2;
+    else if ((unsigned long long)peak * 2ull > capacity) r += 1;
+    return r < 1 ? 1 : (r > kMaxPoolRounds ? kMaxPoolRounds : r);
+}
 
 /* Three-pass launch through a workspace.  Returns RRT_OK after enqueuing, or -1 if the workspace cannot
  * hold this launch's bookkeeping plus a useful pool (the caller then uses the single-kernel path). */
-int launch_deferred(FrameArgs a, bool fast, bool lut, const WorkspaceObject& ws, hipStream_t st) {
+int launch_deferred(FrameArgs a, bool fast, bool lut, const WorkspaceObject& ws, int pool_rounds, hipStream_t st) {
     dim3 block(kWGThreads);
     dim3 grid((a.width + kWGPixX - 1) / kWGPixX, (a.rows.n_local_rows + kWGPixY - 1) / kWGPixY);
     const size_t n_waves = (size_t)grid.x * grid.y * kWGWaves;
@@ -1434,7 +1698,7 @@ int launch_deferred(FrameArgs a, bool fast, bool lut, const WorkspaceObject& ws,
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t off_hdr = 256;
     const size_t off_fin = align(off_hdr + n_waves * sizeof(WaveHdr));
-    const size_t off_rows = align(off_fin + n_lanes * 28);
+    const size_t off_rows = align(off_fin + n_lanes * 4 * kFinalPlanes);
     if (ws.bytes < off_rows + (size_t)1024 * kBlockBytes) return -1;
     size_t cap = (ws.bytes - off_rows) / kBlockBytes;
     if (cap > 0x0fffffffu) cap = 0x0fffffffu;
@@ -1444,24 +1708,35 @@ int launch_deferred(FrameArgs a, bool fast, bool lut, const WorkspaceObject& ws,
     a.n_lanes = n_lanes;
     a.sample_blocks = ws.d_base + off_rows;
     a.block_capacity = (unsigned)cap;
+    const int rounds = pool_rounds > 0 ? pool_rounds : auto_pool_rounds(ws, (unsigned)cap);
     RRT_HIP(hipMemsetAsync(ws.d_base, 0, off_fin, st));            /* counters + wave headers */
     const bool spin = a.spin != 0.0f;
-    if (spin) { if (fast) hipLaunchKernelGGL((march_defer<true, true>), grid, block, 0, st, a);
-                else hipLaunchKernelGGL((march_defer<true, false>), grid, block, 0, st, a); }
-    else      { if (fast) hipLaunchKernelGGL((march_defer<false, true>), grid, block, 0, st, a);
-                else hipLaunchKernelGGL((march_defer<false, false>), grid, block, 0, st, a); }
-    RRT_HIP(hipGetLastError());
+    for (int r = 0; r < rounds; ++r) {
+        const bool last = r == rounds - 1;
+#define RRT_MARCH(S, F) do { if (r == 0) hipLaunchKernelGGL((march_defer<S, F, false>), grid, block, 0, st, a); \
+                             else hipLaunchKernelGGL((march_defer<S, F, true>), grid, block, 0, st, a); } while (0)
+        if (spin) { if (fast) RRT_MARCH(true, true); else RRT_MARCH(true, false); }
+        else      { if (fast) RRT_MARCH(false, true); else RRT_MARCH(false, false); }
+#undef RRT_MARCH
+        RRT_HIP(hipGetLastError());
 #define RRT_EVAL(F, L) hipLaunchKernelGGL((eval_sample_rows<F, L>), dim3(2048), dim3(256), 0, st, a)
-    if (fast) { if (lut) RRT_EVAL(true, true); else RRT_EVAL(true, false); }
-    else      { if (lut) RRT_EVAL(false, true); else RRT_EVAL(false, false); }
+        if (fast) { if (lut) RRT_EVAL(true, true); else RRT_EVAL(true, false); }
+        else      { if (lut) RRT_EVAL(false, true); else RRT_EVAL(false, false); }
 #undef RRT_EVAL
-    RRT_HIP(hipGetLastError());
-#define RRT_COMP(S, F) do { if (lut) hipLaunchKernelGGL((composite_and_shade<S, F, true>), grid, block, 0, st, a); \
-                            else hipLaunchKernelGGL((composite_and_shade<S, F, false>), grid, block, 0, st, a); } while (0)
-    if (spin) { if (fast) RRT_COMP(true, true); else RRT_COMP(true, false); }
-    else      { if (fast) RRT_COMP(false, true); else RRT_COMP(false, false); }
+        RRT_HIP(hipGetLastError());
+#define RRT_COMP3(S, F, L) do { if (last) hipLaunchKernelGGL((composite_and_shade<S, F, L, true>), grid, block, 0, st, a); \
+                                else hipLaunchKernelGGL((composite_and_shade<S, F, L, false>), grid, block, 0, st, a); } while (0)
+#define RRT_COMP(S, F) do { if (lut) RRT_COMP3(S, F, true); else RRT_COMP3(S, F, false); } while (0)
+        if (spin) { if (fast) RRT_COMP(true, true); else RRT_COMP(true, false); }
+        else      { if (fast) RRT_COMP(false, true); else RRT_COMP(false, false); }
 #undef RRT_COMP
-    RRT_HIP(hipGetLastError());
+#undef RRT_COMP3
+        RRT_HIP(hipGetLastError());
+        hipLaunchKernelGGL(pool_next_round, dim3(1), dim3(1), 0, st, a.ctr, a.block_capacity, last ? 1 : 0);
+        RRT_HIP(hipGetLastError());
+    }
+    /* what this launch needed, for the next one's round count (and rrt_workspace_stats) */
+    if (ws.h_stats) RRT_HIP(hipMemcpyAsync(ws.h_stats, ws.d_base, sizeof(DeferCounters), hipMemcpyDeviceToHost, st));
     return RRT_OK;
 }
 
@@ -1473,7 +1748,6 @@ int launch_deferred(FrameArgs a, bool fast, bool lut, const WorkspaceObject& ws,
  * 1/8 (1.04 M rays) 11.7 ms vs 6.8 ms. */
 constexpr long long kThreePassMaxRays = 1500000;
 
-/* media: 0 = off, 1 = on, 2 = on with the lattice-hash tables (a.lut_*) */
 /* room for n tiles in a tile-order object (grows only; growing forgets the order) */
 int tile_order_reserve(TileOrderObject& o, size_t n) {
     if (n <= o.n_cap) return RRT_OK;
@@ -1500,58 +1774,106 @@ int tile_order_reserve(TileOrderObject& o, size_t n) {
     return RRT_OK;
 }
 
-int launch(const FrameArgs& a, int media, bool debug, bool fast, int workspace, int policy, hipStream_t st) {
+/* enqueue the coarse probe of the launch `a` describes (its row map included) into `cells` */
+int enqueue_probe(const FrameArgs& a, ProbeArgs& q, unsigned* cells, int stride_x, int stride_y, hipStream_t st) {
+    q.cell_cost = cells;
+    q.stride_x = stride_x; q.stride_y = stride_y;
+    q.cells_x = (a.width + stride_x - 1) / stride_x;
+    q.cells_y = (a.rows.n_local_rows + stride_y - 1) / stride_y;
+    q.w_step = RRT_PROBE_W_STEP; q.w_acc = RRT_PROBE_W_ACC; q.w_dust = RRT_PROBE_W_DUST;
+    if (const char* e = getenv("RRT_PROBE_WEIGHTS")) {          /* dev: tools/probe_fit.py reads the three counts one at a time */
+        float w0, w1, w2;
+        if (sscanf(e, "%f,%f,%f", &w0, &w1, &w2) == 3) { q.w_step = w0; q.w_acc = w1; q.w_dust = w2; }
+    }
+    const dim3 grid((q.cells_x + 7) / 8, (q.cells_y + 7) / 8);
+    if (a.spin != 0.0f) hipLaunchKernelGGL((probe_costs<true>), grid, dim3(64), 0, st, a, q);
+    else hipLaunchKernelGGL((probe_costs<false>), grid, dim3(64), 0, st, a, q);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+
+int launch(const FrameArgs& a, const LaunchOpts& o, bool debug, hipStream_t st) {
     dim3 block(kWGThreads);
     if (a.rows.n_local_rows == 0) return RRT_OK;
-    if (workspace != 0) {
-        WorkspaceObject ws;
+    const bool spin = a.spin != 0.0f;
+    dim3 grid((a.width + kWGPixX - 1) / kWGPixX, (a.rows.n_local_rows + kWGPixY - 1) / kWGPixY);
+    /* which path */
+    WorkspaceObject ws{};
+    bool deferred = false;
+    if (o.workspace != 0) {
         {
             std::lock_guard<std::mutex> lk(g_ws_mu);
-            auto it = g_ws.find(workspace);
+            auto it = g_ws.find(o.workspace);
             if (it == g_ws.end()) return RRT_ERR_BAD_HANDLE;
             ws = it->second;
         }
         if (!on_current_device(ws.device)) return RRT_ERR_BAD_HANDLE;
         const long long rays = (long long)a.width * a.rows.n_local_rows;
-        const bool want = policy == RRT_PATH_THREE_PASS || (policy == RRT_PATH_AUTO && rays <= kThreePassMaxRays);
-        if (media != 0 && !debug && want && a.max_steps <= kThreePassMaxSteps) {
-            int rc = launch_deferred(a, fast, media == 2, ws, st);
-            if (rc >= 0) return rc;
-        }
+        const bool want = o.policy == RRT_PATH_THREE_PASS || (o.policy == RRT_PATH_AUTO && rays <= kThreePassMaxRays);
+        deferred = o.media != 0 && !debug && want && a.max_steps <= kThreePassMaxSteps;
     }
-    const bool spin = a.spin != 0.0f;
-    dim3 grid((a.width + kWGPixX - 1) / kWGPixX, (a.rows.n_local_rows + kWGPixY - 1) / kWGPixY);
     FrameArgs b = a;
-    /* cost-ordered dispatch: read the order the previous launch through the object left (same geometry only), record
-     * this launch's costs, sort them into the other buffer for the next one */
-    TileOrderObject* order = nullptr;
+    /* cost-ordered dispatch: read the order the previous launch through the object left (same geometry), or -- no history --
+     * the order a coarse probe of this very view gives; record this launch's costs; sort them into the other buffer for the
+     * next one.  A launch that is being captured into a graph renders in the static order and leaves the object alone: a
+     * replayed graph must never read a permutation that a later live launch is rewriting. */
+    std::shared_ptr<TileOrderObject> order;
     std::unique_lock<std::mutex> order_lock;
     const size_t n_tiles = (size_t)grid.x * grid.y;
     if (a.tile_order_id != 0 && !debug && kWGWaves == 1) {
-        order_lock = std::unique_lock<std::mutex>(g_to_mu);
-        auto it = g_to.find(a.tile_order_id);
-        if (it == g_to.end() || !on_current_device(it->second.device)) return RRT_ERR_BAD_HANDLE;
-        order = &it->second;
-        int rc = tile_order_reserve(*order, n_tiles);
-        if (rc != RRT_OK) return rc;
-        if (order->launches > 0) RRT_HIP(hipStreamWaitEvent(st, order->chained, 0));
-        const bool same = order->have && order->grid_x == grid.x && order->grid_y == grid.y && order->width == a.width &&
-                          order->height == a.height && memcmp(&order->rows, &a.rows, sizeof(RowMap)) == 0;
-        b.tile_perm = same ? order->d_perm[order->cur] : nullptr;
-        b.tile_cost = order->d_cost;
-        RRT_HIP(hipMemsetAsync(order->d_cost, 0, n_tiles * sizeof(unsigned), st));
-        if (same) ++order->ordered;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (st != nullptr && hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        if (cap == hipStreamCaptureStatusNone) {
+            order = tile_order_lookup(a.tile_order_id);
+            if (!order || !on_current_device(order->device)) return RRT_ERR_BAD_HANDLE;
+            order_lock = std::unique_lock<std::mutex>(order->mu);
+            if (order->dead) return RRT_ERR_BAD_HANDLE;            /* destroyed while this thread waited for it */
+            int rc = tile_order_reserve(*order, n_tiles);
+            if (rc != RRT_OK) return rc;
+            if (order->launches > 0) RRT_HIP(hipStreamWaitEvent(st, order->chained, 0));
+            const bool same = order->have && order->grid_x == grid.x && order->grid_y == grid.y && order->width == a.width &&
+                              order->height == a.height && same_row_map(order->rows, a.rows);
+            if (!same && !order->no_seed) {
+                /* first launch of this geometry: probe -> per-tile estimate -> order */
+                ProbeArgs q;
+                rc = enqueue_probe(a, q, order->d_sorted, kProbeStride, kProbeStride, st);   /* d_sorted: scratch until the sort */
+                if (rc != RRT_OK) return rc;
+                hipLaunchKernelGGL(probe_to_tiles, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, order->d_cost, grid.x, grid.y, q);
+                RRT_HIP(hipGetLastError());
+                const int next = order->cur ^ 1;
+                size_t tb = order->temp_bytes;
+                RRT_HIP(hipcub::DeviceRadixSort::SortPairsDescending(order->d_temp, tb, order->d_cost, order->d_sorted, order->d_iota,
+                                                                     order->d_perm[next], (int)n_tiles, kTileCostSortLo, kTileCostSortHi, st));
+                order->cur = next;
+                ++order->seeded;
+            }
+            const bool ordered = same || !order->no_seed;
+            b.tile_perm = ordered ? order->d_perm[order->cur] : nullptr;
+            b.tile_cost = order->d_cost;
+            RRT_HIP(hipMemsetAsync(order->d_cost, 0, n_tiles * sizeof(unsigned), st));
+            if (same) ++order->ordered;
+        }
     }
+    bool launched = false;
+    if (deferred) {
+        const int rc = launch_deferred(b, o.fast, o.media == 2, ws, o.pool_rounds, st);
+        if (rc > 0) return rc;
+        launched = rc == RRT_OK;
+    }
+    if (!launched) {
+        const int media = o.media;
+        const bool fast = o.fast;
 #define RRT_LAUNCH4(S, M, D, F) hipLaunchKernelGGL((raymarch_pixels<S, M, D, F>), grid, block, 0, st, b)
 #define RRT_LAUNCH3(S, M, D) do { if (fast) RRT_LAUNCH4(S, M, D, true); else RRT_LAUNCH4(S, M, D, false); } while (0)
 #define RRT_LAUNCH2(S, M) do { if (debug) RRT_LAUNCH3(S, M, true); else RRT_LAUNCH3(S, M, false); } while (0)
 #define RRT_LAUNCH1(S) do { if (media == 2) RRT_LAUNCH2(S, 2); else if (media == 1) RRT_LAUNCH2(S, 1); else RRT_LAUNCH2(S, 0); } while (0)
-    if (spin) RRT_LAUNCH1(true); else RRT_LAUNCH1(false);
+        if (spin) RRT_LAUNCH1(true); else RRT_LAUNCH1(false);
 #undef RRT_LAUNCH1
 #undef RRT_LAUNCH2
 #undef RRT_LAUNCH3
 #undef RRT_LAUNCH4
-    RRT_HIP(hipGetLastError());
+        RRT_HIP(hipGetLastError());
+    }
     if (order) {
         const int next = order->cur ^ 1;
         size_t tb = order->temp_bytes;
@@ -1593,8 +1915,9 @@ const char* rrt_status_string(int s) {
         case RRT_ERR_INVALID_ARGUMENT: return "invalid argument";
         case RRT_ERR_NO_DEVICE: return "no HIP device";
         case RRT_ERR_HIP: return "HIP runtime error";
-        case RRT_ERR_BAD_HANDLE: return "bad handle (sky, workspace, noise table or tile order)";
+        case RRT_ERR_BAD_HANDLE: return "bad handle (sky, workspace, noise table, tile order or tile map)";
         case RRT_ERR_OUT_OF_MEMORY: return "out of memory";
+        case RRT_ERR_ABI_MISMATCH: return "rrt_params from another ABI version (recompile against include/rrt.h)";
         default: return "unknown status";
     }
 }
@@ -1610,15 +1933,29 @@ int rrt_device_count(int* count) {
     return n > 0 ? RRT_OK : RRT_ERR_NO_DEVICE;
 }
 
-int rrt_params_default(rrt_params* p) {
+int rrt_params_default_v4(rrt_params* p) {
     if (!p) return RRT_ERR_INVALID_ARGUMENT;
     memset(p, 0, sizeof(*p));
+    p->struct_size = (uint32_t)sizeof(*p);
     p->spin = 0.0f;          /* SPIN_A    config.h:21 */
     p->max_steps = 2000;     /* MAX_STEPS config.h:48 */
     p->volumetrics = 1;
     p->sky_frac_bits = 8;
     return RRT_OK;
 }
+
+/* The symbol binaries built against the ABI <= 3 header call (include/rrt.h now maps the name to rrt_params_default_v4):
+ * it fills the 36 bytes THEIR struct has -- spin, max_steps, volumetrics, sky_frac_bits, arith_mode, workspace,
+ * path_policy, noise_table, tile_order -- and not a byte more, so such a binary is refused at its first launch
+ * (RRT_ERR_ABI_MISMATCH: its first word is `spin`, not a struct size) instead of having its stack overwritten here. */
+#undef rrt_params_default
+int rrt_params_default(void* legacy36) {
+    if (!legacy36) return RRT_ERR_INVALID_ARGUMENT;
+    int32_t w[9] = {0, 2000, 1, 8, 0, 0, 0, 0, 0};
+    memcpy(legacy36, w, sizeof(w));
+    return RRT_OK;
+}
+#define rrt_params_default rrt_params_default_v4
 
 int rrt_effects_default(rrt_effects* e) {    /* camera_settings.h:5-16 */
     if (!e) return RRT_ERR_INVALID_ARGUMENT;
@@ -1672,9 +2009,12 @@ int rrt_sky_destroy(rrt_sky_t sky) {
 
 int rrt_workspace_create(size_t bytes, int* out) {
     if (!out || bytes < (size_t)1 << 20) return RRT_ERR_INVALID_ARGUMENT;
-    WorkspaceObject w{nullptr, bytes, current_device()};
+    WorkspaceObject w{nullptr, bytes, current_device(), nullptr};
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&w.d_base), bytes);
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(workspace)");
+    e = hipHostMalloc(reinterpret_cast<void**>(&w.h_stats), sizeof(DeferCounters), hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipFree(w.d_base); return hip_fail(e, "hipHostMalloc(workspace statistics)"); }
+    memset(w.h_stats, 0, sizeof(DeferCounters));
     std::lock_guard<std::mutex> lk(g_ws_mu);
     *out = g_ws_next++;
     g_ws.emplace(*out, w);
@@ -1683,31 +2023,44 @@ int rrt_workspace_create(size_t bytes, int* out) {
 
 int rrt_tile_order_create(int* out) {
     if (!out) return RRT_ERR_INVALID_ARGUMENT;
-    TileOrderObject o;
-    memset(&o, 0, sizeof(o));
-    o.device = current_device();
-    RRT_HIP(hipEventCreateWithFlags(&o.chained, hipEventDisableTiming));
+    auto o = std::make_shared<TileOrderObject>();
+    o->device = current_device();
+    o->d_cost = o->d_sorted = o->d_iota = o->d_perm[0] = o->d_perm[1] = nullptr;
+    o->d_temp = nullptr; o->temp_bytes = 0; o->n_cap = 0; o->cur = 0; o->have = false;
+    o->grid_x = o->grid_y = 0; o->width = o->height = 0; o->rows = RowMap{0, 0, 1, 0, 1, nullptr};
+    o->launches = o->ordered = o->seeded = 0; o->no_seed = false; o->dead = false;
+    RRT_HIP(hipEventCreateWithFlags(&o->chained, hipEventDisableTiming));
     std::lock_guard<std::mutex> lk(g_to_mu);
     *out = g_to_next++;
     g_to.emplace(*out, o);
     return RRT_OK;
 }
 
+int rrt_tile_order_set_seeding(int id, int on) {
+    const std::shared_ptr<TileOrderObject> o = tile_order_lookup(id);
+    if (!o) return RRT_ERR_BAD_HANDLE;
+    std::lock_guard<std::mutex> lk(o->mu);
+    o->no_seed = on == 0;
+    return RRT_OK;
+}
+
 int rrt_tile_order_destroy(int id) {
-    TileOrderObject o;
+    std::shared_ptr<TileOrderObject> o;
     {
         std::lock_guard<std::mutex> lk(g_to_mu);
         auto it = g_to.find(id);
         if (it == g_to.end()) return RRT_ERR_BAD_HANDLE;
-        if (!on_current_device(it->second.device)) return RRT_ERR_BAD_HANDLE;
+        if (!on_current_device(it->second->device)) return RRT_ERR_BAD_HANDLE;
         o = it->second;
         g_to.erase(it);
     }
-    if (o.launches > 0) (void)hipEventSynchronize(o.chained);      /* its last launch and sort have finished */
-    unsigned* bufs[] = {o.d_cost, o.d_sorted, o.d_iota, o.d_perm[0], o.d_perm[1]};
+    std::lock_guard<std::mutex> lk(o->mu);                          /* after any launch that holds the object */
+    o->dead = true;
+    if (o->launches > 0) (void)hipEventSynchronize(o->chained);     /* its last launch and sort have finished */
+    unsigned* bufs[] = {o->d_cost, o->d_sorted, o->d_iota, o->d_perm[0], o->d_perm[1]};
     for (unsigned* b : bufs) if (b) (void)hipFree(b);
-    if (o.d_temp) (void)hipFree(o.d_temp);
-    (void)hipEventDestroy(o.chained);
+    if (o->d_temp) (void)hipFree(o->d_temp);
+    (void)hipEventDestroy(o->chained);
     return RRT_OK;
 }
 
@@ -1715,10 +2068,10 @@ int rrt_tile_order_destroy(int id) {
  * use plus the costs the last one recorded: perm_host / cost_host may be NULL, capacity counts elements */
 int rrt_tile_order_info(int id, unsigned long long* launches, unsigned long long* ordered_launches, unsigned* n_tiles,
                         unsigned* perm_host, unsigned* cost_host, unsigned capacity) {
-    std::lock_guard<std::mutex> lk(g_to_mu);
-    auto it = g_to.find(id);
-    if (it == g_to.end()) return RRT_ERR_BAD_HANDLE;
-    const TileOrderObject& o = it->second;
+    const std::shared_ptr<TileOrderObject> op = tile_order_lookup(id);
+    if (!op) return RRT_ERR_BAD_HANDLE;
+    std::lock_guard<std::mutex> lk(op->mu);
+    const TileOrderObject& o = *op;
     if (!on_current_device(o.device)) return RRT_ERR_BAD_HANDLE;
     const unsigned n = o.have ? o.grid_x * o.grid_y : 0u;
     if (launches) *launches = o.launches;
@@ -1733,6 +2086,15 @@ int rrt_tile_order_info(int id, unsigned long long* launches, unsigned long long
     return RRT_OK;
 }
 
+/* launches whose order came from the coarse probe (no history for their geometry) */
+int rrt_tile_order_seeded(int id, unsigned long long* seeded_launches) {
+    const std::shared_ptr<TileOrderObject> o = tile_order_lookup(id);
+    if (!o || !seeded_launches) return o ? RRT_ERR_INVALID_ARGUMENT : RRT_ERR_BAD_HANDLE;
+    std::lock_guard<std::mutex> lk(o->mu);
+    *seeded_launches = o->seeded;
+    return RRT_OK;
+}
+
 /* Parameters of the reference-signature entry point launch_raymarch() (include/raymarcher.h), which has no
  * parameter for them: config.h defaults until the application says otherwise.  Nothing is allocated here --
  * a workspace or noise table named in the defaults is created (and destroyed) by the caller. */
@@ -1743,10 +2105,9 @@ bool g_defaults_set = false;
 int rrt_set_launch_defaults(const rrt_params* prm) {
     std::lock_guard<std::mutex> lk(g_defaults_mu);
     if (!prm) { g_defaults_set = false; return RRT_OK; }
-    if (prm->max_steps < 0 || prm->sky_frac_bits < 0 || prm->sky_frac_bits > 16 || !(prm->spin == prm->spin) ||
-        (prm->arith_mode != RRT_ARITH_STRICT && prm->arith_mode != RRT_ARITH_FAST) || prm->workspace < 0 ||
-        prm->path_policy < RRT_PATH_AUTO || prm->path_policy > RRT_PATH_THREE_PASS || prm->noise_table < 0 || prm->tile_order < 0)
-        return RRT_ERR_INVALID_ARGUMENT;
+    int rc = check_params_abi(prm);
+    if (rc == RRT_OK) rc = check_params_values(prm);
+    if (rc != RRT_OK) return rc;
     g_defaults = *prm;
     g_defaults_set = true;
     return RRT_OK;
@@ -1793,6 +2154,7 @@ int rrt_workspace_destroy(int id) {
         g_ws.erase(it);
     }
     hipError_t e = hipFree(w.d_base);
+    if (w.h_stats) (void)hipHostFree(w.h_stats);
     if (e != hipSuccess) return hip_fail(e, "hipFree(workspace)");
     return RRT_OK;
 }
@@ -1808,8 +2170,27 @@ int rrt_workspace_stats(int id, unsigned* rows_used, unsigned* overflow_waves) {
     if (!on_current_device(w.device)) return RRT_ERR_BAD_HANDLE;
     DeferCounters c;
     RRT_HIP(hipMemcpy(&c, w.d_base, sizeof(c), hipMemcpyDeviceToHost));
-    if (rows_used) *rows_used = c.next_block * kBlockRows;
-    if (overflow_waves) *overflow_waves = c.overflow_waves;
+    const unsigned long long rows = c.total_blocks * kBlockRows;
+    if (rows_used) *rows_used = rows > 0xffffffffull ? 0xffffffffu : (unsigned)rows;
+    if (overflow_waves) *overflow_waves = c.suspended_left;
+    return RRT_OK;
+}
+
+int rrt_workspace_rounds(int id, unsigned* rounds_enqueued, unsigned* rounds_with_work, unsigned* peak_rows, unsigned* pool_rows) {
+    WorkspaceObject w;
+    {
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        auto it = g_ws.find(id);
+        if (it == g_ws.end()) return RRT_ERR_BAD_HANDLE;
+        w = it->second;
+    }
+    if (!on_current_device(w.device)) return RRT_ERR_BAD_HANDLE;
+    DeferCounters c;
+    RRT_HIP(hipMemcpy(&c, w.d_base, sizeof(c), hipMemcpyDeviceToHost));
+    if (rounds_enqueued) *rounds_enqueued = c.rounds_run;
+    if (rounds_with_work) *rounds_with_work = c.rounds_with_work;
+    if (peak_rows) *peak_rows = c.peak_blocks * kBlockRows;
+    if (pool_rows) *pool_rows = (unsigned)((w.bytes / kBlockBytes) * kBlockRows);      /* upper bound: before the launch's bookkeeping */
     return RRT_OK;
 }
 
@@ -1928,7 +2309,11 @@ int rrt_noise_table_fit_window(float t_from, float t_until, size_t budget_bytes,
 }
 
 /* test hook: make every device check see `device` as the current one (< 0: ask HIP again) */
-int rrt_debug_fake_device(int device) { g_fake_device.store(device < 0 ? -1 : device); return RRT_OK; }
+int rrt_debug_fake_device(int device) {
+    if (!test_hooks_enabled()) return RRT_ERR_INVALID_ARGUMENT;
+    g_fake_device.store(device < 0 ? -1 : device);
+    return RRT_OK;
+}
 
 int rrt_launch_raymarch_rows(void* d_out_rows, int width, int height, int y0, int y1, float time,
                              const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx,
@@ -1937,12 +2322,11 @@ int rrt_launch_raymarch_rows(void* d_out_rows, int width, int height, int y0, in
     if (rc) return rc;
     if (y0 < 0 || y1 > height || y0 > y1) return RRT_ERR_INVALID_ARGUMENT;
     FrameArgs a;
-    int media; bool fast;
-    int wsid, policy;
-    rc = fill_args(a, media, fast, wsid, policy, d_out_rows, width, height, time, cam, sky, fx, prm);
+    LaunchOpts o;
+    rc = fill_args(a, o, d_out_rows, width, height, time, cam, sky, fx, prm);
     if (rc) return rc;
-    a.rows = RowMap{y1 - y0, y0, y1 - y0 > 0 ? y1 - y0 : 1, 0, 1};
-    return launch(a, media, false, fast, wsid, policy, static_cast<hipStream_t>(stream));
+    a.rows = RowMap{y1 - y0, y0, y1 - y0 > 0 ? y1 - y0 : 1, 0, 1, nullptr};
+    return launch(a, o, false, static_cast<hipStream_t>(stream));
 }
 
 int rrt_launch_raymarch(void* d_out_rgba8, int width, int height, float time, const rrt_camera* cam,
@@ -1956,13 +2340,12 @@ int rrt_launch_raymarch_ex(void* d_out_rgba8, int width, int height, float time,
     int rc = check_common(d_out_rgba8, width, height, cam, fx, prm);
     if (rc) return rc;
     FrameArgs a;
-    int media; bool fast;
-    int wsid, policy;
-    rc = fill_args(a, media, fast, wsid, policy, d_out_rgba8, width, height, time, cam, sky, fx, prm);
+    LaunchOpts o;
+    rc = fill_args(a, o, d_out_rgba8, width, height, time, cam, sky, fx, prm);
     if (rc) return rc;
-    a.rows = RowMap{height, 0, height, 0, 1};
+    a.rows = RowMap{height, 0, height, 0, 1, nullptr};
     if (dbg) a.dbg = *dbg;
-    return launch(a, media, dbg != nullptr, fast, wsid, policy, static_cast<hipStream_t>(stream));
+    return launch(a, o, dbg != nullptr, static_cast<hipStream_t>(stream));
 }
 
 int rrt_tile_shard_rows(int height, int tile_rows, int shard, int n_shards, int* rows) {
@@ -1979,12 +2362,11 @@ int rrt_launch_raymarch_tiles(void* d_out_tiles, int width, int height, int tile
     if (rc) return rc;
     if (tile_rows <= 0 || n_shards <= 0 || shard < 0 || shard >= n_shards) return RRT_ERR_INVALID_ARGUMENT;
     FrameArgs a;
-    int media; bool fast;
-    int wsid, policy;
-    rc = fill_args(a, media, fast, wsid, policy, d_out_tiles, width, height, time, cam, sky, fx, prm);
+    LaunchOpts o;
+    rc = fill_args(a, o, d_out_tiles, width, height, time, cam, sky, fx, prm);
     if (rc) return rc;
-    a.rows = RowMap{shard_rows(height, tile_rows, shard, n_shards), 0, tile_rows, shard, n_shards};
-    return launch(a, media, false, fast, wsid, policy, static_cast<hipStream_t>(stream));
+    a.rows = RowMap{shard_rows(height, tile_rows, shard, n_shards), 0, tile_rows, shard, n_shards, nullptr};
+    return launch(a, o, false, static_cast<hipStream_t>(stream));
 }
 
 int rrt_assemble_tiles(void* d_frame, const void* d_tiles, int width, int height, int tile_rows, int shard,
@@ -1992,7 +2374,7 @@ int rrt_assemble_tiles(void* d_frame, const void* d_tiles, int width, int height
     if (!d_frame || !d_tiles || width <= 0 || height <= 0 || tile_rows <= 0 || n_shards <= 0 || shard < 0 ||
         shard >= n_shards)
         return RRT_ERR_INVALID_ARGUMENT;
-    RowMap m{shard_rows(height, tile_rows, shard, n_shards), 0, tile_rows, shard, n_shards};
+    RowMap m{shard_rows(height, tile_rows, shard, n_shards), 0, tile_rows, shard, n_shards, nullptr};
     if (m.n_local_rows == 0) return RRT_OK;
     dim3 grid((width + 255) / 256, m.n_local_rows < kMaxGridY ? m.n_local_rows : kMaxGridY);
     hipLaunchKernelGGL(assemble_tiles_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
@@ -2011,6 +2393,182 @@ int rrt_assemble_all_tiles(void* d_frame, const void* d_tiles_all, size_t shard_
     hipLaunchKernelGGL(assemble_all_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<uchar4*>(d_frame), static_cast<const uchar4*>(d_tiles_all), shard_stride_bytes / 4,
                        width, height, tile_rows, n_shards);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+
+/* ---- explicit tile -> shard assignment (rrt_tile_map) ---- */
+int rrt_tile_map_create(int height, int tile_rows, int n_shards, const int32_t* shard_of_tile, int* out_id) {
+    if (!shard_of_tile || !out_id || height <= 0 || tile_rows <= 0 || n_shards <= 0) return RRT_ERR_INVALID_ARGUMENT;
+    const int n_tiles = (height + tile_rows - 1) / tile_rows;
+    auto m = std::make_shared<TileMapObject>();
+    m->height = height; m->tile_rows = tile_rows; m->n_shards = n_shards; m->n_tiles = n_tiles;
+    m->device = current_device();
+    m->shard_of_tile.assign(shard_of_tile, shard_of_tile + n_tiles);
+    m->offset.assign(n_shards + 1, 0);
+    m->rows.assign(n_shards, 0);
+    for (int t = 0; t < n_tiles; ++t) {
+        const int sh = shard_of_tile[t];
+        if (sh < 0 || sh >= n_shards) return RRT_ERR_INVALID_ARGUMENT;
+        ++m->offset[sh + 1];
+        m->rows[sh] += (t + 1) * tile_rows <= height ? tile_rows : height - t * tile_rows;
+    }
+    for (int sh = 0; sh < n_shards; ++sh) m->offset[sh + 1] += m->offset[sh];
+    /* device image: [tile_of_local, grouped by shard, increasing t | shard_of_tile | k_of_tile] */
+    std::vector<int> img(3 * (size_t)n_tiles), fill(m->offset.begin(), m->offset.end() - 1);
+    for (int t = 0; t < n_tiles; ++t) {
+        const int sh = shard_of_tile[t], k = fill[sh] - m->offset[sh];
+        img[fill[sh]++] = t;
+        img[n_tiles + t] = sh;
+        img[2 * (size_t)n_tiles + t] = k;
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_img), img.size() * sizeof(int));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(tile map)");
+    e = hipMemcpy(m->d_img, img.data(), img.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(m->d_img); return hip_fail(e, "hipMemcpy(tile map)"); }
+    std::lock_guard<std::mutex> lk(g_tm_mu);
+    *out_id = g_tm_next++;
+    g_tm.emplace(*out_id, m);
+    return RRT_OK;
+}
+
+int rrt_tile_map_destroy(int id) {
+    std::shared_ptr<TileMapObject> m;
+    {
+        std::lock_guard<std::mutex> lk(g_tm_mu);
+        auto it = g_tm.find(id);
+        if (it == g_tm.end()) return RRT_ERR_BAD_HANDLE;
+        m = it->second;
+        g_tm.erase(it);
+    }
+    hipError_t e = hipFree(m->d_img);
+    if (e != hipSuccess) return hip_fail(e, "hipFree(tile map)");
+    return RRT_OK;
+}
+
+int rrt_tile_map_shard_rows(int id, int shard, int* rows, int* max_rows) {
+    const std::shared_ptr<TileMapObject> m = tile_map_lookup(id);
+    if (!m) return RRT_ERR_BAD_HANDLE;
+    if (shard < 0 || shard >= m->n_shards) return RRT_ERR_INVALID_ARGUMENT;
+    if (rows) *rows = m->rows[shard];
+    if (max_rows) { int mx = 0; for (int r : m->rows) mx = r > mx ? r : mx; *max_rows = mx; }
+    return RRT_OK;
+}
+
+/* Deal row tiles to shards by cost: longest-processing-time-first greedy -- tiles in decreasing cost (ties: increasing
+ * index), each to the shard with the smallest load so far (ties: fewest rows, then lowest index).  Deterministic host
+ * arithmetic in double: every rank computes the same map from the same costs, no exchange needed.  max_tiles_per_shard
+ * (0: none) bounds the buffer a shard needs: ceil(n_tiles / n_shards) + slack is typical. */
+int rrt_tile_map_balance(int n_tiles, const float* tile_cost, int n_shards, int max_tiles_per_shard, int32_t* shard_of_tile_out) {
+    if (n_tiles <= 0 || n_shards <= 0 || !tile_cost || !shard_of_tile_out || max_tiles_per_shard < 0) return RRT_ERR_INVALID_ARGUMENT;
+    if (max_tiles_per_shard > 0 && (long long)max_tiles_per_shard * n_shards < n_tiles) return RRT_ERR_INVALID_ARGUMENT;
+    std::vector<int> idx(n_tiles);
+    for (int t = 0; t < n_tiles; ++t) {
+        if (!(tile_cost[t] >= 0.0f) || !(tile_cost[t] < 3.0e38f)) return RRT_ERR_INVALID_ARGUMENT;    /* NaN, negative, infinite */
+        idx[t] = t;
+    }
+    std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return tile_cost[x] > tile_cost[y]; });
+    std::vector<double> load(n_shards, 0.0);
+    std::vector<int> count(n_shards, 0);
+    for (int t : idx) {
+        int best = -1;
+        for (int sh = 0; sh < n_shards; ++sh) {
+            if (max_tiles_per_shard > 0 && count[sh] >= max_tiles_per_shard) continue;
+            if (best < 0 || load[sh] < load[best] || (load[sh] == load[best] && count[sh] < count[best])) best = sh;
+        }
+        shard_of_tile_out[t] = best;
+        load[best] += (double)tile_cost[t];
+        ++count[best];
+    }
+    return RRT_OK;
+}
+
+int rrt_launch_raymarch_tilemap(void* d_out_tiles, int width, int height, int tile_map, int shard, float time,
+                                const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx, const rrt_params* prm, void* stream) {
+    int rc = check_common(d_out_tiles, width, height, cam, fx, prm);
+    if (rc) return rc;
+    const std::shared_ptr<TileMapObject> m = tile_map_lookup(tile_map);
+    if (!m || !on_current_device(m->device)) return RRT_ERR_BAD_HANDLE;
+    if (m->height != height || shard < 0 || shard >= m->n_shards) return RRT_ERR_INVALID_ARGUMENT;
+    FrameArgs a;
+    LaunchOpts o;
+    rc = fill_args(a, o, d_out_tiles, width, height, time, cam, sky, fx, prm);
+    if (rc) return rc;
+    a.rows = RowMap{m->rows[shard], 0, m->tile_rows, shard, m->n_shards, m->d_img + m->offset[shard]};
+    return launch(a, o, false, static_cast<hipStream_t>(stream));
+}
+
+int rrt_assemble_all_tilemap(void* d_frame, const void* d_tiles_all, size_t shard_stride_bytes, int width, int height,
+                             int tile_map, void* stream) {
+    if (!d_frame || !d_tiles_all || width <= 0 || height <= 0 || (shard_stride_bytes & 3) != 0) return RRT_ERR_INVALID_ARGUMENT;
+    const std::shared_ptr<TileMapObject> m = tile_map_lookup(tile_map);
+    if (!m || !on_current_device(m->device)) return RRT_ERR_BAD_HANDLE;
+    if (m->height != height) return RRT_ERR_INVALID_ARGUMENT;
+    for (int r : m->rows) if (shard_stride_bytes / 4 < (size_t)r * width) return RRT_ERR_INVALID_ARGUMENT;
+    dim3 grid((width + 255) / 256, height < kMaxGridY ? height : kMaxGridY);
+    hipLaunchKernelGGL(assemble_map_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<uchar4*>(d_frame),
+                       static_cast<const uchar4*>(d_tiles_all), shard_stride_bytes / 4, width, height, m->tile_rows,
+                       m->d_img + m->n_tiles, m->d_img + 2 * (size_t)m->n_tiles);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+
+/* Estimated cost of every row tile of the frame, from the coarse march-only probe (one ray per 16 pixels in x, per
+ * min(16, tile_rows) rows in y): what rrt_tile_map_balance wants for a frame nobody has rendered yet.  Synchronous (it
+ * returns host numbers); allocates and frees its own scratch.  The unit is the tile-order object's (wave clocks / 16),
+ * summed over the probe cells of the tile and scaled to the tile's pixel count. */
+int rrt_probe_tile_costs(int width, int height, int tile_rows, float time, const rrt_camera* cam, const rrt_effects* fx,
+                         const rrt_params* prm, float* tile_cost_host, int n_tiles, void* stream) {
+    if (!tile_cost_host || tile_rows <= 0 || !cam || !fx || width <= 0 || height <= 0) return RRT_ERR_INVALID_ARGUMENT;
+    if (n_tiles != (height + tile_rows - 1) / tile_rows) return RRT_ERR_INVALID_ARGUMENT;
+    if (prm) { int rc = check_params_abi(prm); if (rc == RRT_OK) rc = check_params_values(prm); if (rc != RRT_OK) return rc; }
+    rrt_params p;
+    if (prm) p = *prm; else rrt_params_default(&p);
+    FrameArgs a;
+    memset(&a, 0, sizeof(a));
+    a.width = width; a.height = height; a.time = time; a.cam = *cam;
+    a.use_lens = fx->use_lens_distortion != 0; a.distortion_amount = fx->distortion_amount;
+    a.spin = p.spin; a.drag_c = (2.0f * p.spin) * 2.0f; a.max_steps = p.max_steps;
+    a.rows = RowMap{height, 0, height, 0, 1, nullptr};
+    const int sy = tile_rows < kProbeStride ? tile_rows : kProbeStride;
+    ProbeArgs q;
+    const int cells_x = (width + kProbeStride - 1) / kProbeStride, cells_y = (height + sy - 1) / sy;
+    unsigned* d_cells = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_cells), (size_t)cells_x * cells_y * sizeof(unsigned));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(probe)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = enqueue_probe(a, q, d_cells, kProbeStride, sy, st);
+    std::vector<unsigned> cells((size_t)cells_x * cells_y);
+    if (rc == RRT_OK) {
+        e = hipMemcpyAsync(cells.data(), d_cells, cells.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = hip_fail(e, "probe read-back");
+    }
+    (void)hipFree(d_cells);
+    if (rc != RRT_OK) return rc;
+    for (int t = 0; t < n_tiles; ++t) {
+        const int y0 = t * tile_rows, y1 = (t + 1) * tile_rows < height ? (t + 1) * tile_rows : height;
+        double sum = 0.0; int n = 0;
+        for (int cy = y0 / sy; cy * sy < y1 && cy < cells_y; ++cy) {
+            const int yc = cy * sy + sy / 2 < height ? cy * sy + sy / 2 : height - 1;     /* the row the cell was probed at */
+            if (yc < y0 || yc >= y1) continue;
+            for (int cx = 0; cx < cells_x; ++cx) sum += (double)cells[(size_t)cy * cells_x + cx];
+            ++n;
+        }
+        if (n == 0) {        /* no probe row inside the tile (only when tile_rows does not divide the stride): nearest one */
+            const int cy = (y0 + y1) / 2 / sy < cells_y ? (y0 + y1) / 2 / sy : cells_y - 1;
+            for (int cx = 0; cx < cells_x; ++cx) sum += (double)cells[(size_t)cy * cells_x + cx];
+            n = 1;
+        }
+        tile_cost_host[t] = (float)(sum / n * (double)(y1 - y0) / (double)kWGPixY);      /* per 8-row wave tile row of the tile */
+    }
+    return RRT_OK;
+}
+
+int rrt_clock_probe(unsigned long long* d_counters2, unsigned duration_us, void* stream) {
+    if (!d_counters2 || duration_us == 0 || duration_us > 2000000u) return RRT_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), d_counters2,
+                       (unsigned long long)duration_us * 100ull);
     RRT_HIP(hipGetLastError());
     return RRT_OK;
 }

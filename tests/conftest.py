@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the library's test hooks (rrt_debug_fake_device) only work in a process that asked for them before loading it
+os.environ.setdefault("RRT_ENABLE_TEST_HOOKS", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -5,6 +5,7 @@
 // available on this pool); nothing here launches a kernel.  Exit code 0 = clean.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -14,12 +15,32 @@
     do { if (!(cond)) { fprintf(stderr, "host exerciser: %s failed (line %d)\n", #cond, __LINE__); return 1; } } while (0)
 
 int main() {
+    setenv("RRT_ENABLE_TEST_HOOKS", "1", 1);          // before the library's first look at it: the fake-device hook
     EXPECT(rrt_abi_version() == RRT_ABI_VERSION);
     for (int s = -2; s < 9; ++s) EXPECT(rrt_status_string(s) != nullptr && strlen(rrt_status_string(s)) > 0);
     EXPECT(rrt_last_hip_error() != nullptr);
     rrt_params prm; rrt_effects fx;
     EXPECT(rrt_params_default(&prm) == RRT_OK && rrt_params_default(nullptr) == RRT_ERR_INVALID_ARGUMENT);
     EXPECT(rrt_effects_default(&fx) == RRT_OK && rrt_effects_default(nullptr) == RRT_ERR_INVALID_ARGUMENT);
+
+    {   // ABI 4: the struct says its own size; another size is refused; the tile dealer on host arithmetic
+        rrt_params q = prm;
+        EXPECT(q.struct_size == sizeof(rrt_params) && rrt_set_launch_defaults(&q) == RRT_OK);
+        q.struct_size = 36;
+        EXPECT(rrt_set_launch_defaults(&q) == RRT_ERR_ABI_MISMATCH && rrt_set_launch_defaults(nullptr) == RRT_OK);
+        std::vector<float> cost(135);
+        std::vector<int32_t> map(135);
+        for (int t = 0; t < 135; ++t) cost[t] = 1.0f + 4.0f * std::exp(-(t - 67) * (t - 67) / 81.0f);
+        EXPECT(rrt_tile_map_balance(135, cost.data(), 8, 0, map.data()) == RRT_OK);
+        EXPECT(rrt_tile_map_balance(135, cost.data(), 8, 17, map.data()) == RRT_OK);
+        EXPECT(rrt_tile_map_balance(135, cost.data(), 8, 16, map.data()) == RRT_ERR_INVALID_ARGUMENT);
+        EXPECT(rrt_tile_map_balance(0, cost.data(), 8, 0, map.data()) == RRT_ERR_INVALID_ARGUMENT);
+        cost[5] = NAN;
+        EXPECT(rrt_tile_map_balance(135, cost.data(), 8, 0, map.data()) == RRT_ERR_INVALID_ARGUMENT);
+        EXPECT(rrt_tile_map_destroy(77) == RRT_ERR_BAD_HANDLE);
+        int rows = 0;
+        EXPECT(rrt_tile_map_shard_rows(77, 0, &rows, nullptr) == RRT_ERR_BAD_HANDLE);
+    }
 
     // ---- noise-table planning: windows of either sign, every coverage, refusals, the drivers' policy
     size_t bytes = 0; int boxes[12];

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.rrt_abi_version() == 3
+    assert lib.rrt_abi_version() == 4
 
 
 def test_library_exports_launch_raymarch_as_a_cpp_symbol():
@@ -174,7 +174,8 @@ def test_struct_layouts_match_the_reference_structs():
     assert [offs[k] for k in ("use_bloom", "bloom_threshold", "bloom_intensity", "use_vignette",
                               "vignette_intensity", "use_chromatic_aberration", "ca_amount",
                               "use_lens_distortion", "distortion_amount")] == [0, 4, 8, 12, 16, 20, 24, 28, 32]
-    assert C.sizeof(_lib.rrt_params) == 36          # ABI 3: + tile_order
+    assert C.sizeof(_lib.rrt_params) == 44          # ABI 4: struct_size first, pool_rounds last
+    assert _lib.rrt_params.struct_size.offset == 0 and _lib.rrt_params.spin.offset == 4
 
 
 def test_defaults_are_the_reference_defaults():
@@ -195,7 +196,7 @@ def test_status_strings_and_host_side_errors():
     lib = _lib.load()
     assert lib.rrt_status_string(0) == b"ok"
     assert lib.rrt_status_string(1) == b"invalid argument"
-    assert lib.rrt_params_default(None) == 1
+    assert lib.rrt_params_default_v4(None) == 1
     assert lib.rrt_effects_default(None) == 1
     assert lib.rrt_sky_destroy(0) == 4
     assert lib.rrt_sky_create(None, 4, 4, None) == 1
@@ -225,10 +226,76 @@ def test_tile_order_argument_checks_need_no_gpu():
     from relativisticraytracer_amd import _lib
     lib = _lib.load()
     prm = _lib.rrt_params()
-    assert lib.rrt_params_default(C.byref(prm)) == 0
-    assert prm.tile_order == 0 and C.sizeof(_lib.rrt_params) == 36
+    assert lib.rrt_params_default_v4(C.byref(prm)) == 0
+    assert prm.tile_order == 0 and prm.struct_size == C.sizeof(_lib.rrt_params)
     prm.tile_order = -1
     assert lib.rrt_set_launch_defaults(C.byref(prm)) == 1          # RRT_ERR_INVALID_ARGUMENT
     assert lib.rrt_tile_order_create(None) == 1
     assert lib.rrt_tile_order_destroy(12345) == 4                  # RRT_ERR_BAD_HANDLE
     assert lib.rrt_tile_order_info(12345, None, None, None, None, None, 0) == 4
+
+
+def test_params_from_another_abi_are_refused_not_believed():
+    """ABI 4: rrt_params leads with its own size.  A struct of another size -- a binary built against the
+    ABI <= 3 header, whose struct began with `spin` -- is RRT_ERR_ABI_MISMATCH at every entry point that takes one, and the
+    symbol such a binary calls for its defaults still exists and writes the 36 bytes ITS struct has, not one more."""
+    import ctypes as C
+    import numpy as np
+    from relativisticraytracer_amd import _lib
+    lib = _lib.load()
+    prm = _lib.rrt_params()
+    assert lib.rrt_params_default_v4(C.byref(prm)) == 0 and prm.struct_size == 44 and prm.pool_rounds == 0
+    assert lib.rrt_set_launch_defaults(C.byref(prm)) == 0
+    prm.struct_size = 36
+    assert lib.rrt_set_launch_defaults(C.byref(prm)) == 6           # RRT_ERR_ABI_MISMATCH
+    assert b"ABI" in lib.rrt_status_string(6)
+    assert lib.rrt_set_launch_defaults(None) == 0
+    # the legacy export: 36 bytes, guard bytes behind them untouched
+    legacy = lib.rrt_params_default
+    legacy.restype, legacy.argtypes = C.c_int, [C.c_void_p]
+    buf = np.full(64, 0xAB, np.uint8)
+    assert legacy(buf.ctypes.data) == 0
+    assert np.array_equal(buf[:36].view(np.int32), [0, 2000, 1, 8, 0, 0, 0, 0, 0]) and np.all(buf[36:] == 0xAB)
+    # ... and what it wrote is refused as an ABI-4 struct (first word = spin bits = 0, not a size)
+    old = (C.c_uint8 * 64).from_buffer_copy(buf.tobytes())
+    assert lib.rrt_set_launch_defaults(C.cast(old, C.POINTER(_lib.rrt_params))) == 6
+    prm.struct_size = 44; prm.pool_rounds = -1
+    assert lib.rrt_set_launch_defaults(C.byref(prm)) == 1
+
+
+def test_tile_map_balance_is_deterministic_host_arithmetic():
+    """rrt_tile_map_balance: longest-first to the least-loaded shard.  Costs with a heavy middle (the rows through the hole
+    and the disk): max load within 2 % of the mean where t mod 8 is 9 % off; the tile cap is respected; bad input refused."""
+    import ctypes as C
+    import numpy as np
+    from relativisticraytracer_amd import _lib
+    lib = _lib.load()
+    n, g = 135, 8
+    t = np.arange(n)
+    cost = (1.0 + 4.0 * np.exp(-((t - 67) / 9.0) ** 2) + 0.3 * np.sin(t * 0.7)).astype(np.float32)
+    out = np.zeros(n, np.int32)
+    assert lib.rrt_tile_map_balance(n, cost.ctypes.data, g, 0, out.ctypes.data) == 0
+    load = np.bincount(out, weights=cost, minlength=g)
+    modulo = np.bincount(t % g, weights=cost, minlength=g)
+    assert load.max() / load.mean() < 1.02 < modulo.max() / modulo.mean()
+    out2 = np.zeros(n, np.int32)
+    assert lib.rrt_tile_map_balance(n, cost.ctypes.data, g, 0, out2.ctypes.data) == 0 and np.array_equal(out, out2)
+    assert lib.rrt_tile_map_balance(n, cost.ctypes.data, g, 17, out2.ctypes.data) == 0
+    assert np.bincount(out2, minlength=g).max() <= 17
+    assert lib.rrt_tile_map_balance(n, cost.ctypes.data, g, 16, out2.ctypes.data) == 1       # 8 x 16 < 135 tiles
+    bad = cost.copy(); bad[3] = np.nan
+    assert lib.rrt_tile_map_balance(n, bad.ctypes.data, g, 0, out2.ctypes.data) == 1
+    assert lib.rrt_tile_map_destroy(4242) == 4 and lib.rrt_tile_map_create(0, 16, 8, out.ctypes.data, None) == 1
+
+
+def test_test_hooks_are_off_unless_the_process_asked_for_them():
+    """rrt_debug_fake_device only works in a process started with RRT_ENABLE_TEST_HOOKS=1 (a stray call must
+    not be able to make the device-binding checks lie)."""
+    import subprocess, sys
+    code = ("from relativisticraytracer_amd import _lib; lib = _lib.load(); "
+            "import sys; sys.exit(10 + lib.rrt_debug_fake_device(3))")
+    import os
+    env = dict(os.environ); env.pop("RRT_ENABLE_TEST_HOOKS", None)
+    assert subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env).returncode == 11       # INVALID_ARGUMENT
+    env["RRT_ENABLE_TEST_HOOKS"] = "1"
+    assert subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env).returncode == 10

@@ -281,8 +281,11 @@ def test_three_pass_workspace_path_is_byte_identical(ctx):
                     rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=spin, arith_mode=mode))
                     for pool in (ws, tiny):
                         out = torch.zeros_like(ref)
+                        # pool_rounds = 1 for the small pool: ONE round, so that what does not fit takes the in-line route
+                        # (the rounds themselves: test_three_pass_rounds_reuse_a_small_pool)
                         rrt.launch_raymarch(out, w, h, t, cam, tex, fx,
-                                            rrt.RenderParams(spin=spin, arith_mode=mode, workspace=pool.id, path_policy=2))
+                                            rrt.RenderParams(spin=spin, arith_mode=mode, workspace=pool.id, path_policy=2,
+                                                             pool_rounds=1 if pool is tiny else 0))
                         torch.cuda.synchronize()
                         assert torch.equal(out, ref), (w, h, spin, mode, pool.nbytes, pool.stats())
                     assert ws.stats()["overflow_waves"] == 0 and ws.stats()["rows_used"] > 0
@@ -455,7 +458,8 @@ def test_three_pass_full_size_and_heavy_view(ctx):
             ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
             rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9))
             out = torch.zeros_like(ref)
-            rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, workspace=pool.id, path_policy=2))
+            rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, workspace=pool.id, path_policy=2,
+                                                                             pool_rounds=1 if pool is small else 0))
             torch.cuda.synchronize()
             st = pool.stats()
             assert torch.equal(out, ref), (w, h, st)
@@ -472,6 +476,146 @@ def test_three_pass_full_size_and_heavy_view(ctx):
         assert 0 < big.stats()["rows_used"] < 600000
     finally:
         big.destroy(); small.destroy()
+
+
+def test_three_pass_rounds_reuse_a_small_pool(ctx):
+    """Round 4 (rrt_params.pool_rounds): a pool far too small for the view is used in ROUNDS -- march until it is full,
+    evaluate + composite, resume the suspended wavefronts -- so that no ray takes the in-line route: bytes of the single
+    kernel, overflow_waves == 0, several rounds with work.  With too few rounds the rest finishes in line (same bytes);
+    the automatic round count learns from the previous launch through the same workspace."""
+    import torch
+    g, rrt, tex = ctx
+    fx = rrt.CameraEffects(useChromaticAberration=True)
+    pool = rrt.Workspace(40 << 20)
+    nt = rrt.NoiseTable(16.0)
+    order = rrt.TileOrder()
+    try:
+        for (w, h, pos, yaw, pitch, t, spin) in ((320, 180, (4.2, 0.6, 4.2), -90.0, -5.7, 14.0, 0.9),
+                                                 (257, 131, (35.0, 0.8, 10.0), -106.0, -1.2, 12.5, 0.0)):
+            cam = rrt.CameraState.from_angles(pos, yaw, pitch)
+            ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+            rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=spin))
+            for mode in (0, 1):
+                if mode:
+                    rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=spin, arith_mode=1))
+                seen = []
+                for rounds, table, oid in ((48, 0, 0), (48, nt.id, 0), (2, 0, 0), (1, nt.id, 0), (48, nt.id, order.id), (48, 0, order.id)):
+                    out = torch.zeros_like(ref)
+                    rrt.launch_raymarch(out, w, h, t, cam, tex, fx,
+                                        rrt.RenderParams(spin=spin, arith_mode=mode, workspace=pool.id, path_policy=2,
+                                                         pool_rounds=rounds, noise_table=table, tile_order=oid))
+                    torch.cuda.synchronize()
+                    st = pool.stats()
+                    assert torch.equal(out, ref), (w, h, mode, rounds, st)
+                    assert st["rounds_enqueued"] == rounds
+                    seen.append(st)
+                assert seen[0]["overflow_waves"] == 0 and seen[0]["rounds_with_work"] >= 3, seen[0]
+                assert seen[0]["peak_rows"] <= seen[0]["pool_rows"] and seen[0]["rows_used"] > seen[0]["pool_rows"]
+                assert seen[2]["overflow_waves"] > 0 and seen[3]["overflow_waves"] > 0        # too few rounds: in line
+                assert seen[4]["overflow_waves"] == 0 and seen[5]["overflow_waves"] == 0
+        # automatic: the first launch through a fresh workspace guesses 2 rounds, later ones take what the previous one needed
+        fresh = rrt.Workspace(40 << 20)
+        w, h, t = 320, 180, 14.0
+        cam = rrt.CameraState.from_angles((4.2, 0.6, 4.2), -90.0, -5.7)
+        ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+        rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9))
+        hist = []
+        for _ in range(5):
+            out = torch.zeros_like(ref)
+            rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, workspace=fresh.id, path_policy=2))
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+            hist.append(fresh.stats())
+        assert hist[0]["rounds_enqueued"] == 2 and hist[0]["overflow_waves"] > 0
+        assert hist[-1]["overflow_waves"] == 0 and hist[-1]["rounds_enqueued"] >= hist[-1]["rounds_with_work"], hist
+        fresh.destroy()
+    finally:
+        pool.destroy(); nt.destroy(); order.destroy()
+
+
+def test_tile_maps_probe_and_balance(ctx):
+    """Cost-weighted tile -> shard assignment (rrt_tile_map): the coarse probe's row-tile costs, dealt longest-first, give
+    shards whose estimated loads agree to a few per cent where t mod n is far off; rendering every shard of such a map --
+    single kernel and three-pass -- and ONE rrt_assemble_all_tilemap reproduces the single launch byte for byte; a random
+    map does too."""
+    import torch
+    g, rrt, tex = ctx
+    fx = rrt.CameraEffects()
+    ws = rrt.Workspace(512 << 20)
+    try:
+        for (w, h, R, G, cam, t) in ((640, 360, 8, 8, rrt.CameraState.default(), 1.0),
+                                     (500, 281, 16, 3, rrt.CameraState.from_angles((4.2, 0.6, 4.2), -90.0, -5.7), 14.0)):
+            prm = rrt.RenderParams(spin=0.9)
+            full = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+            rrt.launch_raymarch(full, w, h, t, cam, tex, fx, prm)
+            cost = rrt.probe_tile_costs(w, h, R, t, cam, fx, prm)
+            n_tiles = (h + R - 1) // R
+            assert cost.shape == (n_tiles,) and (cost > 0).all()
+            assert np.array_equal(cost, rrt.probe_tile_costs(w, h, R, t, cam, fx, prm))        # deterministic
+            dealt = rrt.balance_tiles(cost, G)
+            load = np.bincount(dealt, weights=cost, minlength=G)
+            modulo = np.bincount(np.arange(n_tiles) % G, weights=cost, minlength=G)
+            assert load.max() / load.mean() <= modulo.max() / modulo.mean() + 1e-6
+            rng = np.random.default_rng(9)
+            for assignment in (dealt, rng.integers(0, G, n_tiles).astype(np.int32), np.arange(n_tiles, dtype=np.int32) % G):
+                tm = rrt.TileMap(h, R, G, assignment)
+                stride = tm.max_shard_rows() * w * 4
+                for policy, wsid in ((1, 0), (2, ws.id)):
+                    allbuf = torch.zeros(G * stride, dtype=torch.uint8, device="cuda")
+                    p2 = rrt.RenderParams(spin=0.9, workspace=wsid, path_policy=policy)
+                    for sh in range(G):
+                        assert tm.shard_rows(sh) == sum(min(R, h - tt * R) for tt in range(n_tiles) if assignment[tt] == sh)
+                        rrt.launch_raymarch_tilemap(allbuf[sh * stride:], w, h, tm, sh, t, cam, tex, fx, p2)
+                    frame = torch.zeros_like(full)
+                    rrt.assemble_all_tilemap(frame, allbuf, stride, w, h, tm)
+                    torch.cuda.synchronize()
+                    assert torch.equal(frame, full), (w, h, policy)
+                tm.destroy()
+        with pytest.raises(rrt.RRTError):
+            rrt.TileMap(360, 8, 4, np.full(45, 4, np.int32))          # shard index out of range
+    finally:
+        ws.destroy()
+
+
+def test_first_frame_order_comes_from_the_probe(ctx):
+    """rrt_tile_order without history: the first launch of a geometry is ordered by the coarse probe of the view (seeded
+    launches are counted), later ones by measured costs; rrt_tile_order_set_seeding(0) renders the first frame in the
+    static order.  Same bytes every way, shards included."""
+    import torch
+    g, rrt, tex = ctx
+    fx = rrt.CameraEffects()
+    w, h, t = 640, 360, 14.0
+    cam = rrt.CameraState.from_angles((4.2, 0.6, 4.2), -90.0, -5.7)
+    ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+    rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9))
+    order = rrt.TileOrder()
+    plain = rrt.TileOrder()
+    plain.set_seeding(False)
+    try:
+        for o, want_seeded in ((order, 1), (plain, 0)):
+            for k in range(3):
+                out = torch.zeros_like(ref)
+                rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, tile_order=o.id))
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref), k
+            info = o.info(arrays=True)
+            assert o.seeded_launches() == want_seeded and info["launches"] == 3 and info["ordered_launches"] == 2
+            assert sorted(info["perm"].tolist()) == list(range(info["n_tiles"]))
+        # a shard through the probe-seeded order (the probe runs over the shard's own rows)
+        buf = torch.zeros(rrt.tile_shard_rows(h, 16, 1, 3) * w * 4, dtype=torch.uint8, device="cuda")
+        want = torch.zeros_like(buf)
+        rrt.launch_raymarch_tiles(want, w, h, 16, 1, 3, t, cam, tex, fx, rrt.RenderParams(spin=0.9))
+        rrt.launch_raymarch_tiles(buf, w, h, 16, 1, 3, t, cam, tex, fx, rrt.RenderParams(spin=0.9, tile_order=order.id))
+        torch.cuda.synchronize()
+        assert torch.equal(buf, want) and order.seeded_launches() == 2
+    finally:
+        order.destroy(); plain.destroy()
+
+
+def test_clock_probe_reports_a_plausible_shader_clock(ctx):
+    g, rrt, tex = ctx
+    ghz = rrt.clock_probe_ghz(5000)
+    assert 0.5 < ghz < 2.6, ghz
 
 
 def test_streams_graph_capture_and_borrowed_sky(ctx, sky):
@@ -502,6 +646,27 @@ def test_streams_graph_capture_and_borrowed_sky(ctx, sky):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(b, ref)
+    # a tile-order object under capture: the captured launch renders in the static order and leaves the
+    # object alone, so that live launches through it can rewrite its permutation while the graph is replayed
+    order = rrt.TileOrder()
+    oprm = rrt.RenderParams(spin=0.9, tile_order=order.id)
+    live = torch.zeros_like(ref)
+    rrt.launch_raymarch(live, w, h, 1.0, cam, tex, fx, oprm)          # sizes the object's buffers outside the capture
+    torch.cuda.synchronize()
+    before = order.info()
+    c2 = torch.zeros_like(ref)
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2):
+        rrt.launch_raymarch(c2, w, h, 1.0, cam, tex, fx, oprm)
+    assert order.info() == before                                      # nothing recorded, nothing sorted
+    for _ in range(3):
+        c2.zero_()
+        graph2.replay()
+        rrt.launch_raymarch(live, w, h, 1.0, cam, tex, fx, oprm, stream=side)      # a live launch re-sorts meanwhile
+        torch.cuda.synchronize()
+        assert torch.equal(c2, ref) and torch.equal(live, ref)
+    assert order.info()["launches"] == before["launches"] + 3
+    order.destroy()
     # borrowed device sky
     dsky = torch.from_numpy(sky).cuda()
     hnd = C.c_ulonglong(0)
@@ -849,7 +1014,7 @@ def test_cost_ordered_dispatch_renders_the_same_frames(ctx):
                 perm, cost = info["perm"], info["cost"]
                 assert np.array_equal(np.sort(perm), np.arange(n_tiles, dtype=np.uint32))            # a permutation ...
                 assert np.all(np.diff((cost[perm] >> 6).astype(np.int64)) <= 0) and cost.max() > 0     # ... longest first (in 0.5 us steps)
-        # another geometry: rendered in the static order (nothing to go by), and the object starts over
+        # another geometry: ordered by the coarse probe (round 4; no history to go by), and the object starts over
         w2, h2 = 333, 130
         ref2 = torch.zeros(h2 * w2 * 4, dtype=torch.uint8, device="cuda"); out2 = torch.zeros_like(ref2)
         cam, t = views[0]
@@ -873,7 +1038,7 @@ def test_cost_ordered_dispatch_renders_the_same_frames(ctx):
                                           rrt.RenderParams(spin=0.9, noise_table=nt.id, tile_order=order.id), stream=streams[k % 2])
         torch.cuda.synchronize()
         assert torch.equal(sout[0], sref) and torch.equal(sout[1], sref)
-        # the three-pass path and debug launches ignore the object; a wrong id is a bad handle
+        # the three-pass path takes the object too (round 4), debug launches ignore it; a wrong id is a bad handle
         ws = rrt.Workspace(256 << 20)
         rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=ws.id, path_policy=2, tile_order=order.id))
         rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id))
