@@ -141,7 +141,9 @@ def self_launch(n, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env["MASTER_ADDR"] = "127.0.0.1"
+    from relativisticraytracer_amd.sharding import single_node_environment      # plain Python: does not touch torch or the GPU
+    single_node_environment(env)                           # RCCL warnings on, loopback bootstrap, dmabuf IPC
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
     for ln in proc.stdout:
@@ -168,6 +170,11 @@ def main():
                     help="N > 1: frames rendered / gathered / assembled concurrently per rank (>= 2; 1 = no pipelining)")
     ap.add_argument("--workspace-gib", type=int, default=16,
                     help="per-rank pool for the three-pass path (N > 1), split between the frames in flight")
+    ap.add_argument("--init-timeout", type=float, default=300.0,
+                    help="N > 1: seconds the process-group / communicator bring-up may take before the run exits non-zero with "
+                         "the tracebacks of all threads (instead of hanging)")
+    ap.add_argument("--run-timeout", type=float, default=900.0,
+                    help="seconds everything after the bring-up may take before the same happens (0: no limit)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -194,12 +201,18 @@ def main():
                  "(RRT_DIST_BACKEND=gloo rehearses several ranks on one card)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dog = sharding.Watchdog(f"bench.py rank {rank}")
     if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # A multi-GPU run must explain itself even when it fails: RCCL warnings on, loopback bootstrap on one
+        # node, RCCL's 0.3 GB library read into the page cache up front (its first collective loads the gfx950 code object out
+        # of it: seconds on a cold cache), a deadline on the bring-up, and a watchdog that ends a stuck run with every thread's
+        # traceback and a non-zero status.
+        sharding.single_node_environment()
+        warm = sharding.warm_library_pages(sharding.torch_rccl_library()) if backend == "nccl" and sharding.torch_rccl_library() else None
+        dog.arm(args.init_timeout, "process group / communicator bring-up")
+        dist = sharding.init_process_group(backend, rank, world, dev, timeout_s=args.init_timeout)
+        if warm is not None:
+            warm.join()
 
     w, h, R = args.width, args.height, args.tile_rows
     sky_np = synthetic_sky(2048, 1024, seed=1)
@@ -227,7 +240,7 @@ def main():
 
     kernel_ms = []
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps + args.warmup)]
+          for _ in range(args.steps + args.warmup + 2)]          # + 2: the untimed frames of the clock measurement
     it = {"i": 0}
 
     def render(buf, slot):
@@ -259,6 +272,8 @@ def main():
         dist.gather(probe, [torch.zeros_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
         dist.barrier()
     torch.cuda.synchronize()
+    dog.disarm()
+    dog.arm(args.run_timeout, "timed frames and their legs")
 
     def barrier():
         torch.cuda.synchronize()
@@ -280,7 +295,25 @@ def main():
         tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    kernel_ms = [a.elapsed_time(b) for a, b in ev[args.warmup:]]
+    kernel_ms = [a.elapsed_time(b) for a, b in ev[args.warmup:args.warmup + args.steps]]
+
+    # The shader clock the chip HOLDS under this very load (boxes of this pool hold 2.21-2.40 GHz, which moved
+    # the roofline fraction by 4 % with nothing in the record to say why).  Untimed: two more frames of the same workload
+    # with rrt_clock_probe beside them on a second stream -- one wavefront that sleeps and reads the shader-clock counter
+    # (s_memtime) and the constant 100 MHz counter (s_memrealtime) at both ends.
+    clock_ghz = None
+    if world == 1:
+        side = torch.cuda.Stream()
+        cbuf = torch.zeros(2, dtype=torch.int64, device=dev)
+        est_ms = float(np.mean(kernel_ms)) if kernel_ms else 40.0
+        side.wait_stream(torch.cuda.current_stream())
+        rrt.clock_probe(cbuf, int(min(2_000_000, max(2_000, 1.7 * est_ms * 1000.0))), stream=side)
+        for _ in range(2):
+            fs.step(); it["i"] += 1
+        torch.cuda.synchronize()
+        cc = cbuf.cpu().numpy()
+        if cc[1] > 0:
+            clock_ghz = float(cc[0]) / float(cc[1]) * 0.1
 
     # N > 1, so that the first real multi-GPU run explains its own efficiency:
     #  - every rank's own phase latencies (render | gather = queueing + waiting for the slowest rank + transfer |
@@ -448,6 +481,11 @@ def main():
                        "comm_ranks": dist.get_world_size() if world > 1 else 1},
             "roofline": {"bound": "valu", "achieved": round(tops, 3), "peak": round(VALU_PEAK_TOPS, 2),
                          "unit": "TFLOP/s", "frac": round(tops / VALU_PEAK_TOPS, 4), "traffic": traffic,
+                         "clock_ghz": round(clock_ghz, 4) if clock_ghz else None,
+                         "frac_at_held_clock": round(tops / (256 * 4 * 32 * clock_ghz * 1e9 / 1e12), 4) if clock_ghz else None,
+                         "clock_note": "shader clock held under this workload: s_memtime / s_memrealtime of a one-wave probe (rrt_clock_probe) "
+                                       "running beside two untimed frames; `peak` prices 2.4 GHz, frac_at_held_clock the clock the chip "
+                                       "actually ran at (boxes of this pool hold 2.2-2.4 GHz)",
                          "traffic_note": traffic_note,
                          "frac_of_fma_peak_157.3": round(tops / 157.3, 4),
                          "kernel": "raymarch_pixels", "kernel_ms": round(k_ms, 3),
@@ -469,9 +507,12 @@ def main():
                                                           "(profiles/r02_frames_in_flight.txt); provisional until a run on >= 2 GPUs"}
         
         print(json.dumps(line), flush=True)
+    dog.disarm()
     if world > 1:
+        dog.arm(60.0, "process group shutdown")
         dist.barrier()
         dist.destroy_process_group()
+        dog.disarm()
     for p in pools:
         p.destroy()
     if ntab:

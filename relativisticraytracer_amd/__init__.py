@@ -26,7 +26,7 @@ __all__ = ["CameraState", "CameraEffects", "RenderParams", "SkyTexture", "Worksp
            "launch_raymarch_rows", "launch_raymarch_tiles", "assemble_tiles", "assemble_all_tiles",
            "tile_shard_rows",
            "launch_raymarch_debug", "RRTError", "device_count", "abi_version", "TileOrder", "TileMap",
-           "probe_tile_costs", "balance_tiles", "launch_raymarch_tilemap", "assemble_all_tilemap", "clock_probe_ghz"]
+           "probe_tile_costs", "balance_tiles", "launch_raymarch_tilemap", "assemble_all_tilemap", "clock_probe", "clock_probe_ghz"]
 
 
 def _ptr(x):
@@ -275,6 +275,12 @@ def balance_tiles(tile_cost, n_shards, max_tiles_per_shard=0):
     _lib.check(_lib.load().rrt_tile_map_balance(len(c), c.ctypes.data, n_shards, max_tiles_per_shard, out.ctypes.data),
                "rrt_tile_map_balance")
     return out
+
+
+def clock_probe(d_counters2, duration_us, stream=None):
+    """rrt_clock_probe, asynchronous: one wavefront sleeps `duration_us` on `stream` and leaves the shader-clock and
+    100 MHz counter deltas in d_counters2 (two int64): d[0] / d[1] * 0.1 = GHz held over that time."""
+    _lib.check(_lib.load().rrt_clock_probe(_ptr(d_counters2), int(duration_us), _stream(stream)), "rrt_clock_probe")
 
 
 def clock_probe_ghz(duration_us=20000, stream=None):

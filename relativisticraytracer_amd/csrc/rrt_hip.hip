@@ -742,6 +742,12 @@ __device__ __forceinline__ unsigned wave_slot(const FrameArgs& a) {
 }
 /* add this wave's lifetime (clocks / 16) to its tile's cost (every lane stores the same word) */
 __device__ __forceinline__ void add_tile_cost(const FrameArgs& a, unsigned long long t_start) {
+#ifdef RRT_WAVE_TIMELINE     /* dev probe (tools/wave_timeline.py): when the wave started and ended, in microseconds mod 65536, instead of its cost */
+    if (RRT_WAVE_TIMELINE == 1) {
+        a.tile_cost[wave_tile(a)] = (unsigned)((t_start / 100ull) & 0xffffull) | ((unsigned)((__builtin_amdgcn_s_memrealtime() / 100ull) & 0xffffull) << 16);
+        return;
+    }
+#endif
     const unsigned long long dt = (__builtin_readcyclecounter() - t_start) >> 4;
     const unsigned t = wave_tile(a);
     const unsigned long long sum = (unsigned long long)a.tile_cost[t] + dt;
@@ -787,10 +793,22 @@ void raymarch_pixels(const FrameArgs a) {
  * the occupancy (measured: 4 waves/SIMD is 15 % slower than 8).
  * RESUME (rounds after the first): only wavefronts the pool ran out under (state 2) do anything -- their suspended rays
  * carry on from the saved pre-step state; rays of the same wave that had already ended stay as they are. */
+#ifndef RRT_DEFER_WAVES
+#define RRT_DEFER_WAVES 8
+#endif
+#if RRT_DEFER_WAVES >= 8
+#define RRT_DEFER_SGPR_ATTR __attribute__((amdgpu_num_sgpr(80)))
+#else
+#define RRT_DEFER_SGPR_ATTR
+#endif
 template <bool SPIN, bool FAST, bool RESUME>
-__global__ __launch_bounds__(kWGThreads, 8) __attribute__((amdgpu_num_sgpr(80))) void march_defer(const FrameArgs a) {
+__global__ __launch_bounds__(kWGThreads, RRT_DEFER_WAVES) RRT_DEFER_SGPR_ATTR void march_defer(const FrameArgs a) {
     if (RESUME && a.ctr->last_overflow == 0u) return;            /* nothing was suspended: the whole grid leaves at once */
+#ifdef RRT_WAVE_TIMELINE
+    const unsigned long long t_start = a.tile_cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#else
     const unsigned long long t_start = a.tile_cost ? __builtin_readcyclecounter() : 0ull;
+#endif
     int x = 0, y = 0, out_row = 0;
     const bool valid = lane_pixel(a, x, y, out_row);
     if (!__any(valid)) return;
@@ -1077,7 +1095,9 @@ __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArg
     if (hit) acc.t = 0.0f;                                         /* raymarcher.cu:49 */
     shade_and_store<false>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, steps);
     if (lane == leader) a.hdr[wid].state = 3u;
+#ifndef RRT_WAVE_TIMELINE
     if (a.tile_cost) add_tile_cost(a, t_start);
+#endif
 }
 
 /* ---- coarse cost probe (round 4): one march-only ray per cell of stride_x x stride_y pixels of the launch's row map.
@@ -1094,12 +1114,18 @@ struct ProbeArgs {
     float w_step, w_acc, w_dust;
 };
 #ifndef RRT_PROBE_W_STEP
-#define RRT_PROBE_W_STEP 170.0f
-#define RRT_PROBE_W_ACC 330.0f
-#define RRT_PROBE_W_DUST 1200.0f
+#define RRT_PROBE_W_STEP 180.0f
+#define RRT_PROBE_W_ACC 730.0f
+#define RRT_PROBE_W_DUST 630.0f
 #endif
 constexpr int kProbeStride = 16;
 
+/* The probe is latency-bound, not throughput-bound: a few hundred wavefronts on a chip with 8 192 wave slots, each a
+ * serial march -- and a lone wavefront retires a dependent instruction every ~10 clocks (profiles/r04_wave_timeline_default.txt),
+ * so a faithful 1000-step march took 1.6 ms however few rays there were.  It therefore marches COARSELY: kProbeStepScale times the
+ * reference's step in every zone (0.3 / 0.09 / 0.03 -> 1.2 / 0.36 / 0.12; classic RK4 is still well inside its accuracy range for
+ * a cost estimate) in the fast arithmetic (FMA, v_rsq): ~0.15 ms.  Every probe step stands for kProbeStepScale real ones. */
+constexpr int kProbeStepScale = 4;
 template <bool SPIN>
 __global__ __launch_bounds__(64) void probe_costs(const FrameArgs a, const ProbeArgs q) {
     const int lane = threadIdx.x & 63;
@@ -1117,41 +1143,30 @@ __global__ __launch_bounds__(64) void probe_costs(const FrameArgs a, const Probe
     float uvx, uvy;
     v3 p, vel;
     primary_ray(a, x, y, uvx, uvy, p, vel);
-    int steps = a.max_steps;
+    const int max_probe = (a.max_steps + kProbeStepScale - 1) / kProbeStepScale;
+    int steps = max_probe;
     unsigned n_acc = 0, n_dust = 0;
-    float ys = 0.0f, hs = 0.0f, hcp = 0.0f;
-    for (int k = 0; k < a.max_steps; ++k) {
+    for (int k = 0; k < max_probe; ++k) {
         const v3 rel_p = p;
-        const float r2 = dot(rel_p, rel_p);
-        float r, yv, hy;
-        const bool rejected = sqrt_seeded_yh<1>(r2, ys, hs, r, yv, hy);
-        const unsigned long long rej_mask = __builtin_amdgcn_ballot_w64(rejected);
-        const bool vacuum = (rej_mask | __builtin_amdgcn_ballot_w64(!(r >= kVacuumR))) == 0ull;
-        if (!vacuum && rej_mask != 0ull) {
-            bool small;
-            if (rejected) radius_fallback(r2, r, yv, hy, small);
-        }
-        if (r < kEventHorizon * 1.01f) { steps = k; break; }
-        if (vacuum) {
-            integrate_rk4_lean<SPIN, true>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, yv, hy, ys, hs, hcp);
-        } else {
-            const bool near_bh = r < 18.0f;
-            const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
-            const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
-            float h, hh, h6;
-            zone_step(near_bh, in_disk, h, hh, h6);
-            integrate_rk4_lean<SPIN, false>(p, vel, h, hh, h6, a.drag_c, r2, r, yv, hy, ys, hs, hcp);
-            if (in_disk || in_cloud) {
-                const float rc2 = rel_p.x * rel_p.x + rel_p.z * rel_p.z;
-                if (rc2 >= kIsco * kIsco && rc2 <= kDiskOut * kDiskOut) {
-                    /* the slab early-out of disk_point(): y^2 rc > 135 ends both densities twelve instructions in */
-                    if (rel_p.y * rel_p.y * rel_p.y * rel_p.y * rc2 <= 135.0f * 135.0f) { n_acc += in_disk; n_dust += in_cloud; }
-                }
+        const float r2 = dot_fma(rel_p, rel_p);
+        const float yv = __builtin_amdgcn_rsqf(r2);
+        const float r = r2 * yv;
+        if (!(r >= kEventHorizon * 1.01f)) { steps = k; break; }              /* horizon (or NaN) */
+        const bool near_bh = r < 18.0f;
+        const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
+        const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
+        const float h = (float)kProbeStepScale * (near_bh ? kHNear : (in_disk ? kHDisk : kHVac));
+        integrate_rk4_fast<SPIN>(p, vel, h, 0.5f * h, h * (1.0f / 6.0f), a.drag_c, r2, yv);
+        if (in_disk || in_cloud) {
+            const float rc2 = rel_p.x * rel_p.x + rel_p.z * rel_p.z;
+            if (rc2 >= kIsco * kIsco && rc2 <= kDiskOut * kDiskOut) {
+                /* the slab early-out of disk_point(): y^2 rc > 135 ends both densities twelve instructions in */
+                if (rel_p.y * rel_p.y * rel_p.y * rel_p.y * rc2 <= 135.0f * 135.0f) { n_acc += in_disk; n_dust += in_cloud; }
             }
         }
         if (r > 250.0f && dot(rel_p, vel) > 0.0f) { steps = k + 1; break; }
     }
-    const float c = q.w_step * (float)steps + q.w_acc * (float)n_acc + q.w_dust * (float)n_dust;
+    const float c = (float)kProbeStepScale * (q.w_step * (float)steps + q.w_acc * (float)n_acc + q.w_dust * (float)n_dust);
     q.cell_cost[cy * q.cells_x + cx] = c >= (float)kTileCostMax ? kTileCostMax : (unsigned)c;
 }
 /* every wave tile (tiles_x x tiles_y of kWGPixX x kWGPixY pixels) takes the cost of the probe cell it lies in */

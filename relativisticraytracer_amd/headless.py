@@ -44,6 +44,10 @@ def main(argv=None):
                     help="per-GPU byte budget of the noise tables: the window of sim time one table covers (and, for long "
                          "sequences, its coverage) is chosen to fit; the table is rebuilt when the clock leaves the window")
     ap.add_argument("--out", default=None, help="x.rgba (raw, bottom-up) | dir/ (PPM per frame) | x.mp4 (needs ffmpeg)")
+    ap.add_argument("--init-timeout", type=float, default=300.0,
+                    help="several ranks: seconds the process-group bring-up may take before the run exits non-zero with "
+                         "the tracebacks of all threads, instead of hanging")
+    ap.add_argument("--frame-timeout", type=float, default=120.0, help="the same for any single frame (0: no limit)")
     args = ap.parse_args(argv)
 
     t_start = time.perf_counter()
@@ -75,12 +79,15 @@ def main(argv=None):
     trace("GPU visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dog = sharding.Watchdog(f"headless.py rank {rank}")
     if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        sharding.single_node_environment()
+        lib = sharding.torch_rccl_library() if backend == "nccl" else None
+        warm = sharding.warm_library_pages(lib) if lib else None
+        dog.arm(args.init_timeout, "process group / communicator bring-up")
+        dist = sharding.init_process_group(backend, rank, world, dev, timeout_s=args.init_timeout)
+        if warm is not None:
+            warm.join()
 
     trace("process group ready" if world > 1 else "single rank")
     w, h = args.width, args.height
@@ -129,6 +136,7 @@ def main(argv=None):
     trace("sky, pools, sink ready; first frame")
     t0 = time.perf_counter()
     for k in range(1, args.frames + 1):
+        dog.arm(args.frame_timeout + (args.init_timeout if k == 1 else 0.0), f"frame {k}")    # frame 1 brings the communicator's channels up
         sim_t, path_t = camera_paths.recording_clock(k, args.fps)
         state["t"] = sim_t
         state["table"] = nwin.table_id(sim_t)
@@ -142,8 +150,10 @@ def main(argv=None):
             deliver(frame)
     torch.cuda.synchronize()
     trace("frames done")
+    dog.arm(args.frame_timeout, "final barrier")
     if world > 1:
         dist.barrier()
+    dog.disarm()
     dt = time.perf_counter() - t0
     if rank == 0:
         if sink:

@@ -16,38 +16,133 @@ oracle as the renderer.
 import numpy as np
 
 
-def tile_plan(height, tile_rows, shard, n_shards):
-    """[(tile index t, first image row y0, rows in tile)] for `shard`, in buffer order."""
+def tile_plan(height, tile_rows, shard, n_shards, shard_of_tile=None):
+    """[(tile index t, first image row y0, rows in tile)] for `shard`, in buffer order (increasing t).
+    shard_of_tile: an explicit assignment (rrt_tile_map; one entry per tile) instead of t mod n_shards."""
     if height <= 0 or tile_rows <= 0 or n_shards <= 0 or not (0 <= shard < n_shards):
         raise ValueError("bad tile plan arguments")
     n_tiles = (height + tile_rows - 1) // tile_rows
-    return [(t, t * tile_rows, min(tile_rows, height - t * tile_rows)) for t in range(shard, n_tiles, n_shards)]
+    if shard_of_tile is None:
+        mine = range(shard, n_tiles, n_shards)
+    else:
+        if len(shard_of_tile) != n_tiles or any(not (0 <= int(v) < n_shards) for v in shard_of_tile):
+            raise ValueError("shard_of_tile: one shard index per row tile")
+        mine = [t for t in range(n_tiles) if int(shard_of_tile[t]) == shard]
+    return [(t, t * tile_rows, min(tile_rows, height - t * tile_rows)) for t in mine]
 
 
-def shard_rows(height, tile_rows, shard, n_shards):
-    return sum(rows for _, _, rows in tile_plan(height, tile_rows, shard, n_shards))
+def shard_rows(height, tile_rows, shard, n_shards, shard_of_tile=None):
+    return sum(rows for _, _, rows in tile_plan(height, tile_rows, shard, n_shards, shard_of_tile))
 
 
-def max_shard_rows(height, tile_rows, n_shards):
-    return max(shard_rows(height, tile_rows, s, n_shards) for s in range(n_shards))
+def max_shard_rows(height, tile_rows, n_shards, shard_of_tile=None):
+    return max(shard_rows(height, tile_rows, s, n_shards, shard_of_tile) for s in range(n_shards))
 
 
-def assemble_numpy(frame, tiles, width, height, tile_rows, shard, n_shards):
-    """Host restatement of rrt_assemble_tiles (used by the CPU tests).
+def assemble_numpy(frame, tiles, width, height, tile_rows, shard, n_shards, shard_of_tile=None):
+    """Host restatement of rrt_assemble_tiles / rrt_assemble_all_tilemap (used by the CPU tests).
     frame: (height, width, 4) bottom-up; tiles: (>= shard_rows, width, 4)."""
-    for k, (t, y0, rows) in enumerate(tile_plan(height, tile_rows, shard, n_shards)):
+    for k, (t, y0, rows) in enumerate(tile_plan(height, tile_rows, shard, n_shards, shard_of_tile)):
         src = tiles[k * tile_rows:k * tile_rows + rows]          # tile-major; tile stored bottom-up
         frame[height - (y0 + rows):height - y0] = src
     return frame
 
 
-def extract_numpy(frame, width, height, tile_rows, shard, n_shards, pad_rows=None):
+def extract_numpy(frame, width, height, tile_rows, shard, n_shards, pad_rows=None, shard_of_tile=None):
     """Inverse of assemble_numpy: the compact tile buffer of `shard` cut from a full frame."""
-    n = shard_rows(height, tile_rows, shard, n_shards)
+    n = shard_rows(height, tile_rows, shard, n_shards, shard_of_tile)
     out = np.zeros((pad_rows if pad_rows is not None else n, width, 4), frame.dtype)
-    for k, (t, y0, rows) in enumerate(tile_plan(height, tile_rows, shard, n_shards)):
+    for k, (t, y0, rows) in enumerate(tile_plan(height, tile_rows, shard, n_shards, shard_of_tile)):
         out[k * tile_rows:k * tile_rows + rows] = frame[height - (y0 + rows):height - y0]
     return out
+
+
+# ---------------------------------------------------------------- bring-up of a multi-rank run (bench.py, headless.py)
+def single_node_environment(env=None):
+    """Defaults for a one-node RCCL job, set only where the caller has not chosen: warnings from RCCL (it says nothing
+    below WARN, and a failing bring-up should explain itself), bootstrap / RAS sockets on the loopback when the
+    rendezvous address is the loopback (RCCL picks the first non-loopback interface by default -- in a container a veth
+    whose state is not this program's business), dmabuf IPC (the only kind this driver stack supports)."""
+    import os
+    env = os.environ if env is None else env
+    env.setdefault("NCCL_DEBUG", "WARN")
+    if env.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+        env.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def warm_library_pages(path):
+    """Read a shared library's file front to back in a background thread, so that its pages sit in the page cache before
+    the loader and the HIP runtime fault them in one by one.  RCCL's library is a 0.3-0.6 GB fat binary; its first
+    collective loads the gfx950 code object out of it -- 5.5 s of a 5.6 s communicator bring-up on a healthy box with a
+    cold cache, minutes on a box whose storage is slow.  Returns the thread (join() is optional)."""
+    import threading
+
+    def read():
+        try:
+            with open(path, "rb", buffering=0) as fh:
+                while fh.read(8 << 20):
+                    pass
+        except OSError:
+            pass
+
+    th = threading.Thread(target=read, name="warm_library_pages", daemon=True)
+    th.start()
+    return th
+
+
+def torch_rccl_library():
+    """Path of the RCCL library torch will load (its bundled one), or None."""
+    import os
+    try:
+        import torch
+    except Exception:
+        return None
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p if os.path.exists(p) else None
+
+
+class Watchdog:
+    """A run that stops making progress ends with a diagnosis instead of hanging: `arm(seconds, what)` (re-)starts a
+    countdown; when it expires the tracebacks of all threads go to stderr with `what` and the process exits with status 1
+    (faulthandler: no Python-level cooperation needed, works inside a blocked collective).  Nothing is retried."""
+
+    def __init__(self, label):
+        self.label = label
+        self.armed = False
+
+    def arm(self, seconds, what):
+        import faulthandler
+        import sys
+        if seconds and seconds > 0:
+            if self.verbose():
+                print(f"[{self.label}] watchdog: {what} (limit {seconds:.0f} s)", file=sys.stderr, flush=True)
+            faulthandler.dump_traceback_later(seconds, repeat=False, file=sys.stderr, exit=True)
+            self.armed = True
+
+    @staticmethod
+    def verbose():
+        import os
+        return bool(os.environ.get("RRT_HEADLESS_TRACE"))
+
+    def disarm(self):
+        import faulthandler
+        if self.armed:
+            faulthandler.cancel_dump_traceback_later()
+            self.armed = False
+
+
+def init_process_group(backend, rank, world, device=None, timeout_s=300.0):
+    """torch.distributed bring-up with a deadline: the store rendezvous and the first collectives fail after `timeout_s`
+    instead of waiting for ever (torch's own default is 10 minutes for nccl, 30 for gloo)."""
+    import datetime
+    import torch.distributed as dist
+    kw = {"rank": rank, "world_size": world, "timeout": datetime.timedelta(seconds=timeout_s)}
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend, **kw)
+    return dist
 
 
 class FrameSharder:
@@ -73,7 +168,7 @@ class FrameSharder:
     """
 
     def __init__(self, width, height, tile_rows, rank, world, device, render, assemble, group=None,
-                 assemble_all=None, pipeline=False, collective_at_world1=False, timing=False):
+                 assemble_all=None, pipeline=False, collective_at_world1=False, timing=False, shard_of_tile=None):
         import torch
         self.torch = torch
         # timing=True (GPU buffers only): device events around the three phases of every step, on the stream the
@@ -83,7 +178,10 @@ class FrameSharder:
         self.events = []
         self.width, self.height, self.tile_rows = width, height, tile_rows
         self.rank, self.world, self.group = rank, world, group
-        self.pad_rows = max_shard_rows(height, tile_rows, world)
+        # shard_of_tile: an explicit tile -> rank assignment (rrt_tile_map: cost-weighted) instead of t mod world; it only
+        # sizes the buffers here -- the callbacks render / assemble with the same map
+        self.shard_of_tile = shard_of_tile
+        self.pad_rows = max_shard_rows(height, tile_rows, world, shard_of_tile)
         self.n_bytes = self.pad_rows * width * 4
         self.render, self.assemble, self.assemble_all = render, assemble, assemble_all
         # collective_at_world1: run the gather path even on a one-rank group (self-checks of the RCCL calls

@@ -52,7 +52,55 @@ def test_extract_assemble_roundtrip():
         assert np.array_equal(out, frame)
 
 
-def _worker(rank, world, port, q, pipeline):
+def test_explicit_tile_maps_cover_every_row_once_and_round_trip():
+    """rrt_tile_map on the host side: any assignment of tiles to shards -- uneven tile counts, an empty shard, a ragged
+    last tile -- covers every row once, and extract / assemble with the map are inverses."""
+    rng = np.random.default_rng(4)
+    h, w, R, n = 45, 13, 7, 4
+    n_tiles = (h + R - 1) // R
+    frame = rng.integers(0, 255, (h, w, 4), dtype=np.uint8)
+    for m in (rng.integers(0, n, n_tiles), np.array([0, 0, 0, 3, 3, 1, 0]), np.arange(n_tiles) % n):
+        seen = np.zeros(h, int)
+        for s in range(n):
+            for t, y0, rows in sh.tile_plan(h, R, s, n, m):
+                assert m[t] == s
+                seen[y0:y0 + rows] += 1
+        assert np.all(seen == 1) and sum(sh.shard_rows(h, R, s, n, m) for s in range(n)) == h
+        out = np.zeros_like(frame)
+        pad = sh.max_shard_rows(h, R, n, m)
+        for s in range(n):
+            sh.assemble_numpy(out, sh.extract_numpy(frame, w, h, R, s, n, pad_rows=pad, shard_of_tile=m), w, h, R, s, n, m)
+        assert np.array_equal(out, frame)
+    with pytest.raises(ValueError):
+        sh.tile_plan(h, R, 0, n, [0] * (n_tiles - 1))
+    with pytest.raises(ValueError):
+        sh.tile_plan(h, R, 0, n, [n] * n_tiles)
+
+
+def test_watchdog_ends_a_stuck_run_with_tracebacks():
+    """sharding.Watchdog: a run that stops making progress exits non-zero and says where every thread sat."""
+    import subprocess
+    code = ("import time, sys; sys.path.insert(0, %r)\n"
+            "from relativisticraytracer_amd.sharding import Watchdog\n"
+            "d = Watchdog('t'); d.arm(30, 'a'); d.disarm(); d.arm(1.0, 'stuck phase')\n"
+            "def stuck():\n    time.sleep(60)\n"
+            "stuck()\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=30)
+    assert r.returncode != 0 and "Timeout (0:00:01)" in r.stderr and "stuck" in r.stderr
+
+
+def test_single_node_environment_only_fills_what_is_unset():
+    env = {"MASTER_ADDR": "127.0.0.1"}
+    sh.single_node_environment(env)
+    assert env["NCCL_DEBUG"] == "WARN" and env["NCCL_SOCKET_IFNAME"] == "lo" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    env = {"MASTER_ADDR": "10.0.0.7", "NCCL_DEBUG": "INFO"}
+    sh.single_node_environment(env)
+    assert env["NCCL_DEBUG"] == "INFO" and "NCCL_SOCKET_IFNAME" not in env
+    th = sh.warm_library_pages(os.path.join(ROOT, "include", "rrt.h")); th.join(10); assert not th.is_alive()
+    sh.warm_library_pages("/nonexistent/file").join(10)
+
+
+def _worker(rank, world, port, q, pipeline, tile_map=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
@@ -70,16 +118,16 @@ def _worker(rank, world, port, q, pipeline):
     def render(buf, slot):      # oracle stands in for rrt_launch_raymarch_tiles; every frame has its own time
         t_sim = times[calls["n"]]; calls["n"] += 1
         full = np.zeros((h, w, 4), np.uint8)
-        for t, y0, rows in sh.tile_plan(h, R, rank, world):
+        for t, y0, rows in sh.tile_plan(h, R, rank, world, tile_map):
             full = po.render(cam, fx, prm, t_sim, w, h, sky, rect=(0, y0, w, y0 + rows), n_threads=1)["rgba8"] | full
-        tiles = sh.extract_numpy(full, w, h, R, rank, world, pad_rows=sh.max_shard_rows(h, R, world))
+        tiles = sh.extract_numpy(full, w, h, R, rank, world, pad_rows=sh.max_shard_rows(h, R, world, tile_map), shard_of_tile=tile_map)
         buf.copy_(torch.from_numpy(tiles.reshape(-1)))
 
     def assemble(frame, buf, shard):
         f = frame.numpy().reshape(h, w, 4)
-        sh.assemble_numpy(f, buf.numpy().reshape(-1, w, 4), w, h, R, shard, world)
+        sh.assemble_numpy(f, buf.numpy().reshape(-1, w, 4), w, h, R, shard, world, tile_map)
 
-    fs = sh.FrameSharder(w, h, R, rank, world, "cpu", render, assemble, pipeline=pipeline)
+    fs = sh.FrameSharder(w, h, R, rank, world, "cpu", render, assemble, pipeline=pipeline, shard_of_tile=tile_map)
     depth = 2 if pipeline is True else int(pipeline or 1)
     got = []
     for k in range(len(times)):
@@ -102,13 +150,14 @@ def _worker(rank, world, port, q, pipeline):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("pipeline", [False, True, 3])
-def test_gather_world2_gloo_matches_single_render(pipeline):
+# the last case: a NON-UNIFORM explicit map (rank 0 gets 5 of the 7 tiles, the ragged last one included): rrt_tile_map's host side
+@pytest.mark.parametrize("pipeline,tile_map", [(False, None), (True, None), (3, None), (3, [0, 1, 0, 0, 1, 0, 0])])
+def test_gather_world2_gloo_matches_single_render(pipeline, tile_map):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, pipeline)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, pipeline, tile_map)) for r in range(2)]
     for p in procs:
         p.start()
     ok = q.get(timeout=240)

@@ -1,0 +1,76 @@
+"""dev tool (GPU): single-GPU projection of an N-way split of a 4K frame -- every shard rendered alone on this GPU
+through the path a rank takes (three-pass pool, noise tables), timed with device events; MAX over the shards is what a
+frame would take on N GPUs (gather / assemble excluded).  Compares tile -> shard assignments and dispatch orders:
+  modulo          tile t -> shard t mod N (rounds 1-3)
+  probe           rrt_probe_tile_costs + rrt_tile_map_balance (what a first frame can know)
+  measured        the tiles' MEASURED costs (rrt_tile_order clocks of the modulo run, summed per row tile), dealt the same way
+each in the static dispatch order and with rrt_tile_order (second launch: ordered by the first one's costs).
+    python tools/shard_maps.py [view] [N] [pool MiB] [spin]      -> profiles/r04_shard_kernel_times_<view>.txt"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import relativisticraytracer_amd as rrt
+from relativisticraytracer_amd.sky import synthetic_sky
+
+VIEWS = {"default": ((0.0, 10.0, -60.0), 0.0, -10.0, 1.0), "key1": ((15.0, 3.0, -30.0), -26.6, -5.1, 6.0),
+         "skimmer": ((4.2, 0.6, 4.2), -90.0, -5.7, 14.0), "grazing": ((35.0, 0.8, 10.0), -106.0, -1.2, 12.0)}
+view = sys.argv[1] if len(sys.argv) > 1 else "default"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+pool_mib = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
+spin = float(sys.argv[4]) if len(sys.argv) > 4 else 0.9
+W, H, R = 3840, 2160, 16
+pos, yaw, pitch, t = VIEWS[view]
+cam = rrt.CameraState.from_angles(pos, yaw, pitch)
+tex = rrt.SkyTexture(synthetic_sky()); fx = rrt.CameraEffects(); nt = rrt.NoiseTable(32.0)
+ws = rrt.Workspace(pool_mib << 20)
+n_tiles = (H + R - 1) // R
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+buf = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+
+def timed(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+full = timed(lambda: rrt.launch_raymarch(buf, W, H, t, cam, tex, fx, rrt.RenderParams(spin=spin, noise_table=nt.id)))
+print(f"# {view} 4K a={spin:g}, {N} shards of {R}-row tiles, three-pass through a {pool_mib} MiB pool, noise tables; single-GPU frame (single kernel) {full:.3f} ms")
+
+def run(assignment, ordered, collect=None):
+    tm = rrt.TileMap(H, R, N, assignment)
+    times, stats = [], []
+    for sh in range(N):
+        order = rrt.TileOrder() if (ordered or collect is not None) else None
+        if order is not None and not ordered:
+            order.set_seeding(False)
+        prm = rrt.RenderParams(spin=spin, noise_table=nt.id, workspace=ws.id, path_policy=2, tile_order=order.id if order else 0)
+        times.append(timed(lambda: rrt.launch_raymarch_tilemap(buf, W, H, tm, sh, t, cam, tex, fx, prm)))
+        stats.append(ws.stats())
+        if collect is not None:
+            info = order.info(arrays=True)
+            rows = tm.shard_rows(sh)
+            c = info["cost"].astype(np.float64).reshape(rows // 8, W // 8)
+            mine = [tt for tt in range(n_tiles) if assignment[tt] == sh]
+            per_tile = c.reshape(len(mine), R // 8, W // 8).sum(axis=(1, 2))
+            for k, tt in enumerate(mine):
+                collect[tt] = per_tile[k]
+        if order is not None:
+            order.destroy()
+    tm.destroy()
+    return times, stats
+
+modulo = (np.arange(n_tiles) % N).astype(np.int32)
+measured = np.zeros(n_tiles)
+base_t, base_s = run(modulo, False, collect=measured)
+probe = rrt.probe_tile_costs(W, H, R, t, cam, fx, rrt.RenderParams(spin=spin))
+maps = {"modulo": modulo, "probe": rrt.balance_tiles(probe, N), "measured": rrt.balance_tiles(measured.astype(np.float32), N)}
+for name, m in maps.items():
+    for ordered in (False, True):
+        ts, st = (base_t, base_s) if (name == "modulo" and not ordered) else run(m, ordered)
+        cnt = np.bincount(m, minlength=N)
+        print(f"{name:9s} {'cost-ordered' if ordered else 'static order'}: max shard {max(ts):.3f} ms  min {min(ts):.3f}  mean {np.mean(ts):.3f}  "
+              f"balance min/max {min(ts) / max(ts):.3f}  -> {full / max(ts):.2f}x of the single-GPU frame;  tiles per shard {cnt.min()}-{cnt.max()}, "
+              f"rounds with work {max(s['rounds_with_work'] for s in st)}, in-line fall-backs {sum(s['overflow_waves'] for s in st)}", flush=True)
