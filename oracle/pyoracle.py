@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(HERE, "librrt_oracle.so")
 REF_UNITS_PATH = os.path.join(HERE, "_ref", "libref_units.so")
 REF_CAMERA_PATH = os.path.join(HERE, "_ref", "libref_camera.so")
 REF_FRAMES_PATH = os.path.join(HERE, "_ref", "libref_frames.so")
+REF_STB_PATH = os.path.join(HERE, "_ref", "libref_stb.so")
 
 MATH_LIBM = 0
 MATH_PORTABLE = 1
@@ -267,6 +268,28 @@ def units():
 
 def ref_available():
     return os.path.exists(REF_UNITS_PATH)
+
+
+def ref_stb_available():
+    return os.path.exists(REF_STB_PATH)
+
+
+def ref_stb_load(path):
+    """stbi_load(path, ..., 4) of the reference's own stb_image (src/main.cpp:240) -> (H, W, 4) uint8, row 0 = top."""
+    dll = C.CDLL(REF_STB_PATH)
+    dll.ref_stbi_load_rgba.restype = C.c_void_p
+    dll.ref_stbi_load_rgba.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    dll.ref_stbi_free.argtypes = [C.c_void_p]
+    dll.ref_stbi_failure_reason.restype = C.c_char_p
+    w, h, n = C.c_int(0), C.c_int(0), C.c_int(0)
+    ptr = dll.ref_stbi_load_rgba(os.fsencode(path), C.byref(w), C.byref(h), C.byref(n))
+    if not ptr:
+        raise RuntimeError(f"stbi_load({path}): {dll.ref_stbi_failure_reason().decode()}")
+    try:
+        out = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(h.value, w.value, 4)).copy()
+    finally:
+        dll.ref_stbi_free(ptr)
+    return out, n.value
 
 
 def ref_units():

@@ -38,9 +38,57 @@ def synthetic_sky(width=2048, height=1024, seed=1):
     return out
 
 
+RAW_MAGIC = b"RRTSKY1\n"
+
+
+def save_sky_raw(path, rgba8):
+    """Write a decoded sky as a raw file: b"RRTSKY1\\n", b"<width> <height>\\n", then height x width RGBA8 texels, row 0 =
+    top -- the bytes stbi_load(..., 4) returns (src/main.cpp:240) and cudaMemcpy2DToArray uploads (:247), so that a sky
+    can be DECODED ONCE with the reference's own decoder and shipped (JPEG decoders differ)."""
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("sky must be an (H, W, 4) uint8 array")
+    with open(path, "wb") as fh:
+        fh.write(RAW_MAGIC + f"{a.shape[1]} {a.shape[0]}\n".encode())
+        fh.write(a.tobytes())
+
+
+def load_sky_raw(path):
+    """Read a raw sky written by save_sky_raw (or tools/sky_to_raw.py): exactly the texels that were decoded, no decoder
+    involved.  Raises ValueError on a file that is not one."""
+    with open(path, "rb") as fh:
+        if fh.read(len(RAW_MAGIC)) != RAW_MAGIC:
+            raise ValueError(f"{path}: not a raw sky (no RRTSKY1 header)")
+        dims = fh.readline(64).split()
+        if len(dims) != 2:
+            raise ValueError(f"{path}: bad raw sky header")
+        w, h = int(dims[0]), int(dims[1])
+        if w <= 0 or h <= 0 or w * h > (1 << 30):
+            raise ValueError(f"{path}: bad raw sky size {w}x{h}")
+        data = fh.read(w * h * 4 + 1)
+    if len(data) != w * h * 4:
+        raise ValueError(f"{path}: raw sky holds {len(data)} bytes, expected {w * h * 4}")
+    return np.frombuffer(data, np.uint8).reshape(h, w, 4).copy()
+
+
+def is_raw_sky(path):
+    try:
+        with open(path, "rb") as fh:
+            return fh.read(len(RAW_MAGIC)) == RAW_MAGIC
+    except OSError:
+        return False
+
+
 def load_sky(path):
-    """Decode an equirectangular image to (H, W, 4) uint8 RGBA, row 0 = top -- what the reference gets
-    from stbi_load(..., 4) (src/main.cpp:240).  Decoders differ by +-1/255 on JPEGs; this uses PIL."""
+    """An equirectangular sky as (H, W, 4) uint8 RGBA, row 0 = top -- what the reference gets from
+    stbi_load(filename, ..., 4) (src/main.cpp:240).
+    A raw sky (save_sky_raw / tools/sky_to_raw.py) is read as it is: texel for texel what the reference's decoder gave.
+    Anything else is decoded with PIL, which is NOT the reference's decoder: on the reference's own asset
+    assets/skyboxes/skybox2.jpg (4096x2048) PIL's libjpeg and stb_image v2.30 disagree on 0.90 % of the colour bytes --
+    by 1 on 226 364 of them, by 2 on 1 397, by 3 on one (tests/golden/sky_ref.npz, tests/test_sky_loader.py).  For a
+    reference-exact render decode once with the reference's decoder and ship the raw file."""
+    if is_raw_sky(path):
+        return load_sky_raw(path)
     from PIL import Image
     with Image.open(path) as im:
         return np.ascontiguousarray(np.asarray(im.convert("RGBA"), dtype=np.uint8))

@@ -32,6 +32,12 @@ stays clear:
                      HIP kernels (integrate_rk4_lean: seed pairs carried from step to step, wave-uniform vacuum step,
                      extrapolated seeds, v_rsq fall-backs) at unit level: rrt_unit_rk4_lean, tests/test_gpu_units.py.
 
+  sky_ref.npz        the reference's sky LOADER: its own assets decoded by its own stb_image
+                     (stbi_load(...,4), src/main.cpp:240; oracle/ref_stb.c) -- sizes, sha256 of the full decodes, six 64x64
+                     crops and one 256x128 crop of skybox2.jpg, the histogram of PIL-minus-stb differences (what this
+                     package's fallback decoder does to the same file), and one frame rendered by the reference's own
+                     kernel body with the 256x128 crop as its sky.
+
     python tests/golden/make_golden.py
 """
 import os
@@ -178,6 +184,51 @@ def make_rk4_chains():
     print("rk4_chain_ref.npz:", len(out), "arrays")
 
 
+SKY_ASSETS = ("skybox2.jpg", "skybox.png")          # /root/reference/assets/skyboxes; main.cpp:497 loads the first
+SKY_CROPS = ((0, 0), (1000, 2016), (512, 3000), (1984, 4032), (900, 100), (1500, 2500))      # (row, col) of the 64x64 crops
+SKY_BIG_CROP = (960, 1920, 128, 256)                # row, col, rows, cols: the sky of the fixture frame below
+
+
+def make_sky():
+    import hashlib
+    from PIL import Image
+    if not po.ref_stb_available():
+        po.build(ref=True)
+    out = {}
+    for name in SKY_ASSETS:
+        path = os.path.join("/root/reference/assets/skyboxes", name)
+        stb, channels = po.ref_stb_load(path)
+        with Image.open(path) as im:
+            pil = np.ascontiguousarray(np.asarray(im.convert("RGBA"), dtype=np.uint8))
+        tag = name.replace(".", "_")
+        out[f"{tag}_size"] = np.int32([stb.shape[1], stb.shape[0], channels])
+        out[f"{tag}_stb_sha256"] = np.frombuffer(hashlib.sha256(stb.tobytes()).digest(), np.uint8)
+        out[f"{tag}_file_sha256"] = np.frombuffer(hashlib.sha256(open(path, "rb").read()).digest(), np.uint8)
+        d = pil[..., :3].astype(np.int16) - stb[..., :3].astype(np.int16)
+        vals, counts = np.unique(d, return_counts=True)
+        out[f"{tag}_pil_minus_stb_values"], out[f"{tag}_pil_minus_stb_counts"] = vals.astype(np.int16), counts.astype(np.int64)
+        out[f"{tag}_alpha_all_255"] = np.bool_((stb[..., 3] == 255).all())
+        print(f"{name}: {stb.shape[1]}x{stb.shape[0]}, PIL differs from stb_image on {100.0 * (d != 0).mean():.2f} % of the colour bytes "
+              f"(max |d| {int(np.abs(d).max())})")
+        if name == SKY_ASSETS[0]:
+            for k, (r, c) in enumerate(SKY_CROPS):
+                out[f"{tag}_crop{k}_at"] = np.int32([r, c]); out[f"{tag}_crop{k}"] = stb[r:r + 64, c:c + 64].copy()
+            r, c, nr, nc = SKY_BIG_CROP
+            big = stb[r:r + nr, c:c + nc].copy()
+            out[f"{tag}_bigcrop_at"] = np.int32(SKY_BIG_CROP); out[f"{tag}_bigcrop"] = big
+            # one frame of the reference's own kernel body with that crop as the sky: the default camera looks past the
+            # hole at the sky, a = 0.9, all four effects (three sky fetches per ray)
+            w, h, spin, vol, camspec, t, fxkw = 96, 54, 0.9, 1, ((0.0, 10.0, -60.0), 0.0, -10.0), 1.0, {"use_ca": 1}
+            cam_arr, _ = frame_camera(camspec)
+            fx = po.default_effects(**fxkw)
+            rr = po.ref_render(cam_arr, fx, spin, vol, t, w, h, big)
+            out["frame_scene"] = np.array([w, h, spin, vol, t], np.float64)
+            out["frame_camera"] = cam_arr
+            out["frame_rgba8"], out["frame_steps"] = rr["rgba8"], rr["steps"].astype(np.int16)
+    np.savez_compressed(os.path.join(HERE, "sky_ref.npz"), **out)
+    print("sky_ref.npz:", len(out), "arrays")
+
+
 def make_camera():
     rc = po.RefCamera()
     rng = np.random.default_rng(7)
@@ -297,8 +348,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rk4_chains":
         make_rk4_chains()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sky":
+        make_sky()
+        sys.exit(0)
     make_units()
     make_camera()
     make_frames()
     make_frames_ref()
     make_rk4_chains()
+    make_sky()

@@ -331,6 +331,48 @@ def test_frames_against_the_reference_kernel(ctx, frames_ref, name):
     assert np.array_equal(prod["rgba8"], r["rgba8"])                                # production instantiation: same bytes
 
 
+def test_frame_with_a_real_sky_against_the_reference_kernel(ctx, po):
+    """a frame whose sky is REAL -- a 256x128 crop of the reference's own asset as the reference's own
+    decoder (stb_image, main.cpp:240) decodes it -- against the frame the reference's kernel body rendered with it
+    (tests/golden/sky_ref.npz), live as well where oracle/_ref travelled, and byte for byte against the oracle."""
+    import os
+    from conftest import GOLDEN
+    g, rrt, _ = ctx
+    ref = dict(np.load(os.path.join(GOLDEN, "sky_ref.npz")))
+    crop = ref["skybox2_jpg_bigcrop"]
+    tex = rrt.SkyTexture(crop)
+    try:
+        w, h, spin, vol, t = ref["frame_scene"]
+        w, h, spin, t = int(w), int(h), float(np.float32(spin)), float(np.float32(t))
+        a = ref["frame_camera"]
+        cam = rrt.CameraState(a[0], a[1], a[2], a[3])
+        fx = rrt.CameraEffects(useChromaticAberration=True)
+        r = g.render_gpu(w, h, spin, int(vol), cam, t, tex, fx=fx)
+        assert np.array_equal(r["steps"], ref["frame_steps"].astype(np.int32))
+        d = np.abs(r["rgba8"].astype(int) - ref["frame_rgba8"].astype(int))
+        assert d.max() <= 1 and (d > 0).sum() <= 1e-4 * d.size + 1, int((d > 0).sum())
+        prod = g.render_gpu(w, h, spin, int(vol), cam, t, tex, fx=fx, debug=False)
+        assert np.array_equal(prod["rgba8"], r["rgba8"])
+        ocam = po.camera(a[0], a[1], a[2], a[3])
+        exact = po.render(ocam, po.default_effects(use_ca=1), po.default_params(spin=spin, volumetrics=int(vol), math_mode=po.MATH_PORTABLE),
+                          t, w, h, crop)["rgba8"]
+        assert np.array_equal(r["rgba8"], exact)
+        if po.ref_frames_available():
+            live = po.ref_render(a, po.default_effects(use_ca=1), spin, int(vol), t, w, h, crop)
+            assert np.array_equal(live["rgba8"], ref["frame_rgba8"])
+        # a raw sky file shipped from the build container is what the package loads (same texels in, same frame out)
+        import tempfile
+        from relativisticraytracer_amd import sky as skymod
+        with tempfile.TemporaryDirectory() as td:
+            skymod.save_sky_raw(os.path.join(td, "s.rrtsky"), crop)
+            tex2 = rrt.SkyTexture(skymod.load_sky(os.path.join(td, "s.rrtsky")))
+            r2 = g.render_gpu(w, h, spin, int(vol), cam, t, tex2, fx=fx, debug=False)
+            tex2.destroy()
+        assert np.array_equal(r2["rgba8"], r["rgba8"])
+    finally:
+        tex.destroy()
+
+
 def test_random_scenes_against_the_reference_kernel_live(ctx, po, sky):
     """HIP path vs the REFERENCE's kernel body rendered live on this host (oracle/_ref/libref_frames.so was compiled
     from /root/reference in the build container and travels with the tree; skipped where it is absent): on seeded
