@@ -366,11 +366,19 @@ class NoiseWindows:
     def __init__(self, t_end, budget_bytes, sync=None, enabled=True):
         self.t_end, self.budget, self.sync, self.enabled = float(t_end), int(budget_bytes), sync, enabled
         self.table = None
+        self.failed = None          # (t0, t1) of a window that could not be built: frames in it hash arithmetically, no retry
+        self.retry_after = 5.0
         self.builds, self.table_frames, self.arith_frames, self.coarsest = 0, 0, 0, TABLE_FULL
         self.peak_bytes = 0
 
     def table_id(self, t):
         if not self.enabled:
+            return 0
+        # a window that could not be built (nothing fits the budget; out of memory) is REMEMBERED: no new fit, no device
+        # synchronise and no retry until the clock has left it -- retrying every frame serialised the frames in flight for
+        # the rest of the run
+        if self.failed is not None and self.failed[0] <= t <= self.failed[1]:
+            self.arith_frames += 1
             return 0
         if self.table is None or not self.table.covers(t):
             t1, cov, nbytes = NoiseTable.fit(t, max(t, self.t_end), self.budget)
@@ -379,6 +387,7 @@ class NoiseWindows:
             if self.table is not None:
                 self.table.destroy()
                 self.table = None
+            self.failed = None
             if nbytes:
                 try:
                     self.table = NoiseTable.window(t, t1, cov)
@@ -386,9 +395,12 @@ class NoiseWindows:
                     self.coarsest = max(self.coarsest, cov)
                     self.peak_bytes = max(self.peak_bytes, nbytes)
                 except _lib.RRTError as e:          # e.g. out of memory: warn once, carry on without
+                    self.failed = (t, t1)
                     if not getattr(self, "_warned", False):
                         print(f"noise table [{t:g}, {t1:g}] not built ({e}); hashing arithmetically", flush=True)
                         self._warned = True
+            else:
+                self.failed = (t, t + self.retry_after)      # nothing fits: look again after retry_after seconds of sim time
         if self.table is not None and self.table.covers(t):
             self.table_frames += 1
             return self.table.id

@@ -1028,7 +1028,15 @@ RRT_DEV float dust_density(v3 p, float time, const NoiseLut& L, unsigned* oob) {
 }
 
 /* Both densities of one in-zone sample as the render kernels need them (raymarcher.cu:68-69): the position-only
- * terms are shared (DiskPoint). */
+ * terms are shared (DiskPoint).
+ * INVARIANT: the outputs are valid ONLY for comparison with the `d > 0.001f` gates of raymarcher.cu:71,76,91.
+ * The early-outs of disk_point / accretion_density_at / dust_density_at (y^2 rc > 135; slab exponent < -10.5;
+ * envelope * 30.02 <= 0.001; n + 2 amp <= 0.7272; envelope * strands <= 9.25e-5) return 0 where the literal functions
+ * return a small density AT OR UNDER the gate -- bit-equal to the literal value wherever that value exceeds the gate, and
+ * merely "<= 0.001" elsewhere.  Every consumer here (sample_emission; the three-pass pool keeps the sample POINTS, never
+ * these values) tests the gate and nothing else.  A new consumer of the raw densities -- a debug density output, say --
+ * must call the literal instantiations (EARLY_OUT / LEAN = false).  Pinned by tests/test_gpu_units.py::
+ * test_early_outs_agree_with_the_literal_densities_through_the_gate on points straddling every threshold. */
 template <bool LUT>
 RRT_DEV void media_densities(v3 p, float time, bool in_disk, bool in_cloud, const NoiseLut& lut_acc, const NoiseLut& lut_dust,
                              unsigned* oob, float& d_disk, float& d_cloud) {

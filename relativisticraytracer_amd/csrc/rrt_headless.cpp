@@ -179,8 +179,7 @@ constexpr int kMaxSlots = 4;   // capacity of the per-slot arrays; --frames-in-f
 struct Device {                // everything one GPU owns
     int id = 0;
     rrt_sky_t sky = 0;
-    int noise_table = 0;
-    float table_t0 = 0.0f, table_t1 = -1.0f;      // window of noise_table (empty: none yet)
+    int noise_table = 0;                          // this device's copy of the current window's table (0: none)
     int pool[kMaxSlots] = {};
     int order[kMaxSlots] = {};                    // rrt_tile_order per slot (0: static dispatch order)
     hipStream_t stream[kMaxSlots] = {};
@@ -250,6 +249,8 @@ int main(int argc, char** argv) {
     int table_builds = 0, table_frames = 0, arith_frames = 0, coarsest = RRT_TABLE_FULL;
     size_t table_peak = 0;
     bool table_warned = false;
+    float win_t0 = 0.0f, win_t1 = -1.0f;         // the window the devices' tables (or the remembered failure) cover; empty at first
+    bool win_has_table = false;
 
     const std::vector<uint8_t> sky = synthetic_sky(2048, 1024, sky_seed);
     rrt_effects fx; rrt_effects_default(&fx);
@@ -352,31 +353,38 @@ int main(int argc, char** argv) {
         // slot reuse: frame k-kSlots used the same buffers; its host copy must have been written out
         if (k > kSlots && deliver(slot)) return 1;
         // 0. noise tables: when the clock has left the window, every device builds the next one (after its frames in
-        //    flight, which may still read the old table, have drained)
-        if (use_table && !(dev[0].noise_table && sim_t >= dev[0].table_t0 && sim_t <= dev[0].table_t1)) {
+        //    flight, which may still read the old table, have drained).  The window is ONE decision for all devices: if it
+        //    cannot be built on any of them (nothing fits the budget, out of memory) it is dropped on all of them and
+        //    REMEMBERED -- no new fit, no device synchronise, no retry until the clock has left it (retrying
+        //    every frame serialised the frames in flight and rebuilt the other devices' tables for nothing).
+        const bool in_window = sim_t >= win_t0 && sim_t <= win_t1;
+        if (use_table && !in_window) {
             float t1 = sim_t; int cov = RRT_TABLE_FULL; size_t bytes = 0;
             rrt_noise_table_fit_window(sim_t, seq_end > sim_t ? seq_end : sim_t, table_budget, &t1, &cov, &bytes);
+            bool ok = bytes != 0;
             for (int d = 0; d < gpus; ++d) {
                 Device& D = dev[d];
                 HIPCHK(hipSetDevice(d));
                 HIPCHK(hipDeviceSynchronize());
                 if (D.noise_table) { rrt_noise_table_destroy(D.noise_table); D.noise_table = 0; }
-                D.table_t0 = sim_t; D.table_t1 = sim_t - 1.0f;
-                if (bytes == 0) continue;
-                if ((rc = rrt_noise_table_create_window(sim_t, t1, cov, &D.noise_table)) != RRT_OK) {
+                if (ok && (rc = rrt_noise_table_create_window(sim_t, t1, cov, &D.noise_table)) != RRT_OK) {
                     D.noise_table = 0;
+                    ok = false;
                     if (!table_warned) {
                         fprintf(stderr, "rrt_headless: noise table [%g, %g] not built on device %d: %s (%s); hashing arithmetically\n",
                                 sim_t, t1, d, rrt_status_string(rc), rrt_last_hip_error());
                         table_warned = true;
                     }
-                    continue;
                 }
-                D.table_t1 = t1;
             }
-            if (dev[0].noise_table) { ++table_builds; if (cov > coarsest) coarsest = cov; if (bytes > table_peak) table_peak = bytes; }
+            if (!ok) {      // all or nothing: the devices must agree on which kernels a frame runs for the timing to mean anything
+                for (int d = 0; d < gpus; ++d) if (dev[d].noise_table) { HIPCHK(hipSetDevice(d)); rrt_noise_table_destroy(dev[d].noise_table); dev[d].noise_table = 0; }
+                if (bytes == 0) t1 = sim_t + 5.0f;          // nothing fits: look again after 5 s of sim time
+            }
+            win_t0 = sim_t; win_t1 = t1; win_has_table = ok;
+            if (ok) { ++table_builds; if (cov > coarsest) coarsest = cov; if (bytes > table_peak) table_peak = bytes; }
         }
-        if (use_table && dev[0].noise_table && sim_t >= dev[0].table_t0 && sim_t <= dev[0].table_t1) ++table_frames; else ++arith_frames;
+        if (use_table && win_has_table) ++table_frames; else ++arith_frames;
         // 1. every device renders its tiles
         for (int d = 0; d < gpus; ++d) {
             Device& D = dev[d];

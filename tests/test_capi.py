@@ -299,3 +299,18 @@ def test_test_hooks_are_off_unless_the_process_asked_for_them():
     assert subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env).returncode == 11       # INVALID_ARGUMENT
     env["RRT_ENABLE_TEST_HOOKS"] = "1"
     assert subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env).returncode == 10
+
+
+def test_noise_windows_remember_a_window_that_cannot_be_built():
+    """a window that cannot be built (here: nothing fits the byte budget) used to be retried on every frame --
+    a fit and a device-wide synchronise per frame, which serialised the frames in flight.  Now the failure is remembered
+    until the clock has left the window: one sync, then none."""
+    import relativisticraytracer_amd as rrt
+    syncs = {"n": 0}
+    nw = rrt.NoiseWindows(t_end=30.0, budget_bytes=1000, sync=lambda: syncs.__setitem__("n", syncs["n"] + 1))
+    ids = [nw.table_id(0.1 * k) for k in range(40)]            # 4 s of sim time, all inside the first remembered window
+    assert ids == [0] * 40 and syncs["n"] == 1 and nw.arith_frames == 40 and nw.builds == 0
+    assert nw.table_id(5.5) == 0 and syncs["n"] == 2           # past the 5 s retry horizon: one new look
+    assert nw.table_id(5.6) == 0 and syncs["n"] == 2
+    off = rrt.NoiseWindows(30.0, 1 << 30, enabled=False)
+    assert off.table_id(1.0) == 0 and off.arith_frames == 0

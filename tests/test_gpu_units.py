@@ -295,6 +295,55 @@ def test_density_functions_with_table_switches_equal_the_arithmetic_ones(g, po, 
         nt.destroy()
 
 
+def test_early_outs_agree_with_the_literal_densities_through_the_gate(g, po):
+    """The render kernels' density functions return 0 early wherever they can PROVE the literal value stays at or under
+    the `d > 0.001f` gates (rrt_device.h: media_densities' invariant).  Points chosen to STRADDLE each threshold -- the slab
+    cut y^2 rc = 135 (+-3 %), the accretion slab exponent -10.5, the rims where the envelopes cross 0.001 / 30.02, thin dust
+    slabs around the base < 0.001 cut of densities.h:85 -- plus random in-zone points: wherever the literal density
+    exceeds the gate the early-out variant has the same bits; elsewhere it is some value <= the gate (and >= 0)."""
+    import torch
+    import relativisticraytracer_amd as rrt
+    rng = np.random.default_rng(77)
+    n = 1 << 16
+    rc = rng.uniform(10.0, 25.0, n); ang = rng.uniform(-np.pi, np.pi, n)
+    y = np.empty(n)
+    q = n // 4
+    y[:q] = np.sqrt(135.0 / rc[:q]) * rng.uniform(0.97, 1.03, q) * rng.choice([-1.0, 1.0], q)            # y^2 rc ~ 135
+    # accretion slab exponent -(y / (0.8 (0.5 + 0.5 (rc - 10) / 15)))^2 ... around -10.5: |y| ~ 3.24 x the local scale height
+    hgt = 0.8 * (0.5 + 0.5 * (rc[q:2 * q] - 10.0) / 15.0)
+    y[q:2 * q] = hgt * np.sqrt(10.5) * rng.uniform(0.9, 1.1, q) * rng.choice([-1.0, 1.0], q)
+    y[2 * q:3 * q] = rng.uniform(-0.75, 0.75, q)                                                             # the dust slab
+    rc[2 * q:3 * q] = np.concatenate([rng.uniform(10.0, 10.6, q // 2), rng.uniform(24.0, 25.0, q - q // 2)])  # rims: envelopes -> 0
+    y[3 * q:] = rng.uniform(-4.0, 4.0, n - 3 * q)
+    pts = np.stack([rc * np.cos(ang), y, rc * np.sin(ang)], 1).astype(np.float32)
+    for t in (0.0, 3.0):
+        nt = rrt.NoiseTable(8.0)
+        try:
+            d = g.dev(pts)
+            got_disk, got_dust = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+            cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+            g.unit("media_lut", n, d, float(t), nt.id, got_disk, got_dust, cnt)
+            lit_disk, lit_dust = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+            g.unit("accretion_density", n, d, float(t), lit_disk)
+            g.unit("dust_density", n, d, float(t), lit_dust)
+            gd, gu, ld, lu = g.host(got_disk), g.host(got_dust), g.host(lit_disk), g.host(lit_dust)
+            r = np.linalg.norm(pts.astype(np.float64), axis=1)
+            in_disk = (np.abs(pts[:, 1]) < 4.0) & (r < 30.0)
+            in_cloud = (np.abs(pts[:, 1]) < 0.75) & (r < 25.0)
+            for got, lit, zone, name in ((gd, ld, in_disk, "disk"), (gu, lu, in_cloud, "dust")):
+                live = (lit > 0.001) & zone
+                assert same_bits(got[live], lit[live]), name
+                dead = ~(lit > 0.001) & zone
+                assert np.all(got[dead] <= 0.001) and np.all(got[dead] >= 0.0), name
+                assert live.sum() > 500 and dead.sum() > 500, (name, int(live.sum()), int(dead.sum()))
+            assert np.all(gd[~in_disk] == 0.0) and np.all(gu[~in_cloud] == 0.0)       # outside the zone the kernels never call
+            # the thresholds really are straddled: early-outs fired on a good share of the sub-gate points
+            assert ((gd == 0.0) & (ld > 0.0) & in_disk).sum() > 1000 and ((gu == 0.0) & (lu > 0.0) & in_cloud).sum() > 100
+            assert int(cnt[0]) == 0
+        finally:
+            nt.destroy()
+
+
 def test_fast_sqrt_is_correctly_rounded_everywhere_it_is_used(g):
     """sqrt_rsq (rsq + Newton + residual fix-up) == IEEE sqrtf for EVERY float in [1, 2^64)."""
     import ctypes as C
