@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 4      /* 4: rrt_params.struct_size (leading) and .pool_rounds, rrt_tile_map_*, rrt_probe_tile_costs,
+#define RRT_ABI_VERSION 4      /* 4: rrt_params.struct_size (leading), .pool_rounds, .pass_chains, rrt_tile_map_*, rrt_probe_tile_costs,
                                      rrt_clock_probe; 3: rrt_params.tile_order, rrt_tile_order_* */
 
 typedef enum {
@@ -120,6 +120,10 @@ typedef struct rrt_params {
                                 serves any view.  0 (default): automatic -- as many rounds as the workspace's previous
                                 launch needed, plus one, at least 2; n > 0: exactly up to n rounds.  Rays still
                                 suspended after the last round finish with the media sampled in line (same bytes).   */
+    int32_t pass_chains;     /* three-pass path: 0 (default) = automatic -- a launch of >= 2 048 wavefronts is cut in two
+                                along its dispatch order and the halves run their march -> evaluate -> composite chains
+                                side by side (the workspace's own second stream), so that one half's evaluation fills the
+                                other half's march tail; 1 = one chain; 2 = two whenever possible.  Same bytes.           */
 } rrt_params;
 
 #define RRT_PATH_AUTO 0

@@ -40,7 +40,7 @@ class rrt_params(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("spin", C.c_float), ("max_steps", C.c_int32), ("volumetrics", C.c_int32),
                 ("sky_frac_bits", C.c_int32), ("arith_mode", C.c_int32), ("workspace", C.c_int32),
                 ("path_policy", C.c_int32), ("noise_table", C.c_int32), ("tile_order", C.c_int32),
-                ("pool_rounds", C.c_int32)]
+                ("pool_rounds", C.c_int32), ("pass_chains", C.c_int32)]
 
 
 class rrt_debug_outputs(C.Structure):

@@ -136,9 +136,14 @@ constexpr unsigned kBlockTrailer = kBlockRows * kRowData;         /* masks[kBloc
 constexpr unsigned kBlockBytes = kBlockTrailer + kBlockRows * 8 + 64;
 constexpr unsigned kNoBlock = 0xffffffffu;
 
+constexpr int kMaxChains = 2;
+constexpr size_t kCounterStride = 64;      /* bytes between the chains' DeferCounters at the head of the workspace */
+static_assert(sizeof(DeferCounters) <= kCounterStride, "one counter block per chain");
 struct WorkspaceObject {
     uint8_t* d_base; size_t bytes; int device;
-    DeferCounters* h_stats;      /* pinned host copy of the counters its last launch left (asynchronous, behind that launch) */
+    DeferCounters* h_stats;      /* pinned host copy (one per chain) of the counters its last launch left (asynchronous, behind that launch) */
+    hipStream_t side;            /* the second chain's stream (round 4), with the two events that fork it from and join it to the caller's */
+    hipEvent_t forked, joined;
 };
 std::mutex g_ws_mu;
 std::unordered_map<int, WorkspaceObject> g_ws;
@@ -341,6 +346,9 @@ struct FrameArgs {
     const unsigned* tile_perm;
     unsigned* tile_cost;
     int tile_order_id;      /* host side only: rrt_params.tile_order */
+    /* a launch that covers only dispatch rows [grid_row_base, grid_row_base + gridDim.y) of a frame's grid_rows rows of
+     * wave tiles (the three-pass path's chains, round 4); grid_rows == 0: the kernel's own grid is the whole launch */
+    int grid_rows, grid_row_base;
 };
 
 /* ------------------------------------------------------------------ explicit tile -> shard maps (rrt_tile_map)
@@ -683,8 +691,9 @@ constexpr int kMaxGridY = 65535;               /* HIP's limit for gridDim.y: a l
 /* Workgroups are dispatched in blockIdx order; the rows through the middle of the frame hold the
  * longest rays (shadow edge, disk), so row-blocks are visited from the middle outwards: mid, mid+1,
  * mid-1, ...  Longest-first shortens the tail of a launch; it changes no pixel. */
-__device__ __forceinline__ int row_block() {
-    const int nb = gridDim.y, j = blockIdx.y, mid = (nb - 1) >> 1;
+__device__ __forceinline__ int dispatch_row(const FrameArgs& a) { return a.grid_row_base + (int)blockIdx.y; }
+__device__ __forceinline__ int row_block(const FrameArgs& a) {
+    const int nb = a.grid_rows ? a.grid_rows : (int)gridDim.y, j = dispatch_row(a), mid = (nb - 1) >> 1;
     return (j & 1) ? mid + ((j + 1) >> 1) : mid - (j >> 1);
 }
 /* Workgroups go to the 8 XCDs round-robin in linear-id order (statically: ids = k mod 8 all run on one XCD), and
@@ -697,13 +706,13 @@ __device__ __forceinline__ int row_block() {
 #ifndef RRT_XCD_RUN
 #define RRT_XCD_RUN 0
 #endif
-__device__ __forceinline__ int tile_column() {
+__device__ __forceinline__ int tile_column(const FrameArgs& a) {
     const int bx = blockIdx.x;
     if (RRT_XCD_RUN <= 0) return bx;
     constexpr int L = RRT_XCD_RUN > 0 ? RRT_XCD_RUN : 1, G = 8 * L;
     const int base = (bx / G) * G;
     if (base + G > (int)gridDim.x) return bx;                 /* the ragged last group keeps its place */
-    const unsigned id = blockIdx.y * gridDim.x + bx;          /* dispatch order: id % 8 labels the XCD */
+    const unsigned id = (unsigned)dispatch_row(a) * gridDim.x + bx;          /* dispatch order: id % 8 labels the XCD */
     return base + (int)(id & 7u) * L + (((bx - base) >> 3) % L);
 }
 /* A wave tile's cost is its lifetime in shader clocks / 16, clamped to 22 bits (a wave that lives 30 ms); the order only
@@ -714,14 +723,14 @@ constexpr int kTileCostSortLo = 6, kTileCostSortHi = 22;
 /* the wave tile (row_block * gridDim.x + column) this workgroup renders: the static order above, or the launch's
  * cost-ordered permutation */
 __device__ __forceinline__ unsigned wave_tile(const FrameArgs& a) {
-    if (a.tile_perm) return a.tile_perm[blockIdx.y * gridDim.x + blockIdx.x];
-    return (unsigned)(row_block() * (int)gridDim.x + tile_column());
+    if (a.tile_perm) return a.tile_perm[(unsigned)dispatch_row(a) * gridDim.x + blockIdx.x];
+    return (unsigned)(row_block(a) * (int)gridDim.x + tile_column(a));
 }
 __device__ __forceinline__ bool lane_pixel(const FrameArgs& a, int& x, int& y, int& out_row) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int col, rb;
     if (a.tile_perm) { const unsigned t = wave_tile(a); rb = (int)(t / gridDim.x); col = (int)(t - (unsigned)rb * gridDim.x); }
-    else { col = tile_column(); rb = row_block(); }
+    else { col = tile_column(a); rb = row_block(a); }
     x = col * kWGPixX + (wave & 1) * kTileW + (lane & (kTileW - 1));
     const int lr = rb * kWGPixY + (wave >> 1) * kTileH + lane / kTileW;
     return x < a.width && map_row(a.rows, a.height, lr, y, out_row);
@@ -881,7 +890,10 @@ __global__ __launch_bounds__(kWGThreads, RRT_DEFER_WAVES) RRT_DEFER_SGPR_ATTR vo
                 const float rc2 = rel_p.x * rel_p.x + 0.0f * 0.0f + rel_p.z * rel_p.z;
                 float rc, rci;
                 sqrt_rsq(rc2, rc, rci);
-                need = rc2 >= 1.0f && !(rc < kIsco || rc > kDiskOut);
+                /* ... and, inside the gate, unless y^2 rc > 135 -- disk_point()'s first exact early-out, the same
+                 * expression on the same correctly rounded rc: such a sample evaluates to the identity, so it is not
+                 * pooled at all (round 4: a third fewer rows on the bench view, whose rays cross the |y| < 4 zone steeply) */
+                need = rc2 >= 1.0f && !(rc < kIsco || rc > kDiskOut) && !((rel_p.y * rel_p.y) * rc > 135.0f);
             }
             need_mask = __ballot(need);
         }
@@ -1112,6 +1124,7 @@ struct ProbeArgs {
     unsigned* cell_cost;       /* cells_y x cells_x */
     int cells_x, cells_y, stride_x, stride_y;
     float w_step, w_acc, w_dust;
+    float ring_steps;          /* max_steps: what a wave on the critical curve marches */
 };
 #ifndef RRT_PROBE_W_STEP
 #define RRT_PROBE_W_STEP 180.0f
@@ -1146,12 +1159,13 @@ __global__ __launch_bounds__(64) void probe_costs(const FrameArgs a, const Probe
     const int max_probe = (a.max_steps + kProbeStepScale - 1) / kProbeStepScale;
     int steps = max_probe;
     unsigned n_acc = 0, n_dust = 0;
+    bool captured = false;
     for (int k = 0; k < max_probe; ++k) {
         const v3 rel_p = p;
         const float r2 = dot_fma(rel_p, rel_p);
         const float yv = __builtin_amdgcn_rsqf(r2);
         const float r = r2 * yv;
-        if (!(r >= kEventHorizon * 1.01f)) { steps = k; break; }              /* horizon (or NaN) */
+        if (!(r >= kEventHorizon * 1.01f)) { steps = k; captured = true; break; }              /* horizon (or NaN) */
         const bool near_bh = r < 18.0f;
         const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
         const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
@@ -1167,7 +1181,11 @@ __global__ __launch_bounds__(64) void probe_costs(const FrameArgs a, const Probe
         if (r > 250.0f && dot(rel_p, vel) > 0.0f) { steps = k + 1; break; }
     }
     const float c = (float)kProbeStepScale * (q.w_step * (float)steps + q.w_acc * (float)n_acc + q.w_dust * (float)n_dust);
-    q.cell_cost[cy * q.cells_x + cx] = c >= (float)kTileCostMax ? kTileCostMax : (unsigned)c;
+    /* bit 0: the ray ended on the horizon.  Cells whose neighbours disagree about that hold the CRITICAL CURVE (the edge
+     * of the shadow), whose rays orbit until MAX_STEPS: a ring a pixel or two wide that a sample every 16 pixels mostly
+     * misses, and the longest waves of the frame (probe_to_tiles prices those cells at max_steps). */
+    const unsigned ci = c >= (float)kTileCostMax ? kTileCostMax : (unsigned)c;
+    q.cell_cost[cy * q.cells_x + cx] = (ci & ~1u) | (captured ? 1u : 0u);
 }
 /* every wave tile (tiles_x x tiles_y of kWGPixX x kWGPixY pixels) takes the cost of the probe cell it lies in */
 __global__ __launch_bounds__(256) void probe_to_tiles(unsigned* tile_cost, unsigned tiles_x, unsigned tiles_y, ProbeArgs q) {
@@ -1176,7 +1194,25 @@ __global__ __launch_bounds__(256) void probe_to_tiles(unsigned* tile_cost, unsig
     const unsigned rb = t / tiles_x, col = t - rb * tiles_x;
     int cx = (int)(col * kWGPixX) / q.stride_x, cy = (int)(rb * kWGPixY) / q.stride_y;
     cx = cx < q.cells_x ? cx : q.cells_x - 1; cy = cy < q.cells_y ? cy : q.cells_y - 1;
-    tile_cost[t] = q.cell_cost[cy * q.cells_x + cx];
+    const unsigned own = q.cell_cost[cy * q.cells_x + cx];
+    unsigned cost = own;
+    /* 3 x 3 neighbourhood: the largest estimate (thin structures between samples), and -- where captured and escaping
+     * samples meet -- the cost of a wave that marches to max_steps */
+    bool mixed = false;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int nx = cx + dx, ny = cy + dy;
+            if (nx < 0 || ny < 0 || nx >= q.cells_x || ny >= q.cells_y) continue;
+            const unsigned c = q.cell_cost[ny * q.cells_x + nx];
+            mixed = mixed || ((c ^ own) & 1u);
+            cost = c > cost ? c : cost;
+        }
+    if (mixed) {
+        const float ring = q.w_step * q.ring_steps;
+        const unsigned rc = ring >= (float)kTileCostMax ? kTileCostMax : (unsigned)ring;
+        cost = rc > cost ? rc : cost;
+    }
+    tile_cost[t] = cost;
 }
 
 /* one wavefront sleeps for `ticks` of the 100 MHz counter and reports both counters' deltas (rrt_clock_probe) */
@@ -1611,6 +1647,7 @@ int check_params_values(const rrt_params* prm) {
     if (prm->path_policy < RRT_PATH_AUTO || prm->path_policy > RRT_PATH_THREE_PASS) return RRT_ERR_INVALID_ARGUMENT;
     if (prm->noise_table < 0 || prm->tile_order < 0) return RRT_ERR_INVALID_ARGUMENT;
     if (prm->pool_rounds < 0 || prm->pool_rounds > 64) return RRT_ERR_INVALID_ARGUMENT;
+    if (prm->pass_chains < 0 || prm->pass_chains > kMaxChains) return RRT_ERR_INVALID_ARGUMENT;
     return RRT_OK;
 }
 int check_common(const void* out, int width, int height, const rrt_camera* cam, const rrt_effects* fx,
@@ -1626,7 +1663,7 @@ int check_common(const void* out, int width, int height, const rrt_camera* cam, 
     return RRT_OK;
 }
 
-struct LaunchOpts { int media; bool fast; int workspace, policy, pool_rounds; };
+struct LaunchOpts { int media; bool fast; int workspace, policy, pool_rounds, pass_chains; };
 
 int fill_args(FrameArgs& a, LaunchOpts& o, void* out, int width, int height, float time, const rrt_camera* cam,
               rrt_sky_t sky, const rrt_effects* fx, const rrt_params* prm_in) {
@@ -1648,6 +1685,7 @@ int fill_args(FrameArgs& a, LaunchOpts& o, void* out, int width, int height, flo
     a.max_steps = prm.max_steps;
     memset(&a.dbg, 0, sizeof(a.dbg));
     a.tile_perm = nullptr; a.tile_cost = nullptr; a.tile_order_id = prm.tile_order;
+    a.grid_rows = 0; a.grid_row_base = 0;
     if (prm.tile_order != 0) {                      /* whatever path the launch takes: a stale or foreign id is an error */
         const std::shared_ptr<TileOrderObject> to = tile_order_lookup(prm.tile_order);
         if (!to || !on_current_device(to->device)) return RRT_ERR_BAD_HANDLE;
@@ -1674,6 +1712,7 @@ int fill_args(FrameArgs& a, LaunchOpts& o, void* out, int width, int height, flo
     o.workspace = prm.workspace;
     o.policy = prm.path_policy;
     o.pool_rounds = prm.pool_rounds;
+    o.pass_chains = prm.pass_chains;
     a.ctr = nullptr; a.hdr = nullptr; a.finals = nullptr; a.n_lanes = 0; a.sample_blocks = nullptr; a.block_capacity = 0;
     return RRT_OK;
 }
@@ -1690,41 +1729,25 @@ constexpr int kMaxPoolRounds = 64;
 /* How many rounds to enqueue (rrt_params.pool_rounds == 0).  The host cannot ask the device without stalling the
  * stream, so it reads the statistics the workspace's PREVIOUS launch left in pinned host memory (an asynchronous copy
  * behind its last kernel; possibly a frame stale, which is all an animation needs): as many rounds as that launch had
- * work for, one more if its fullest round used over half the pool, twice as many if rays were still suspended at its
- * end.  An idle round costs three near-empty launches (every wave leaves on one scalar load). */
-int auto_pool_rounds(const WorkspaceObject& ws, unsigned capacity) {
-    if (!ws.h_stats) return 2;
-    const volatile DeferCounters* h = ws.h_stats;
+ * work for PLUS ONE spare (a view that changes finds room; an idle round costs three near-empty launches, ~20 us: every
+ * wave leaves on one scalar load), twice as many plus one if rays were still suspended at its end.  Rays the enqueued
+ * rounds do not finish take the in-line route: the bytes never depend on the guess. */
+int auto_pool_rounds(const volatile DeferCounters* h, unsigned capacity) {
+    if (!h) return 2;
     const unsigned run = h->rounds_run, work = h->rounds_with_work, left = h->suspended_left, peak = h->peak_blocks;
     if (run == 0u) return 2;                                    /* no history */
+    (void)peak; (void)capacity;
     int r = (int)(work > 0u ? work : 1u);
-    if (left != 0u) r *= 2;
-    else if ((unsigned long long)peak * 2ull > capacity) r += 1;
-    return r < 1 ? 1 : (r > kMaxPoolRounds ? kMaxPoolRounds : r);
+    r = left != 0u ? 2 * r + 1 : r + 1;
+    return r > kMaxPoolRounds ? kMaxPoolRounds : r;
 }
 
-/* Three-pass launch through a workspace.  Returns RRT_OK after enqueuing, or -1 if the workspace cannot
- * hold this launch's bookkeeping plus a useful pool (the caller then uses the single-kernel path). */
-int launch_deferred(FrameArgs a, bool fast, bool lut, const WorkspaceObject& ws, int pool_rounds, hipStream_t st) {
-    dim3 block(kWGThreads);
-    dim3 grid((a.width + kWGPixX - 1) / kWGPixX, (a.rows.n_local_rows + kWGPixY - 1) / kWGPixY);
-    const size_t n_waves = (size_t)grid.x * grid.y * kWGWaves;
-    const size_t n_lanes = n_waves * 64;
-    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t off_hdr = 256;
-    const size_t off_fin = align(off_hdr + n_waves * sizeof(WaveHdr));
-    const size_t off_rows = align(off_fin + n_lanes * 4 * kFinalPlanes);
-    if (ws.bytes < off_rows + (size_t)1024 * kBlockBytes) return -1;
-    size_t cap = (ws.bytes - off_rows) / kBlockBytes;
-    if (cap > 0x0fffffffu) cap = 0x0fffffffu;
-    a.ctr = reinterpret_cast<DeferCounters*>(ws.d_base);
-    a.hdr = reinterpret_cast<WaveHdr*>(ws.d_base + off_hdr);
-    a.finals = reinterpret_cast<float*>(ws.d_base + off_fin);
-    a.n_lanes = n_lanes;
-    a.sample_blocks = ws.d_base + off_rows;
-    a.block_capacity = (unsigned)cap;
-    const int rounds = pool_rounds > 0 ? pool_rounds : auto_pool_rounds(ws, (unsigned)cap);
-    RRT_HIP(hipMemsetAsync(ws.d_base, 0, off_fin, st));            /* counters + wave headers */
+/* one chain = march -> evaluate -> composite (in rounds) over dispatch rows [row0, row1) of the launch, in its own slice
+ * of the pool, on its own stream */
+int enqueue_chain(FrameArgs a, bool fast, bool lut, dim3 full_grid, int row0, int row1, int rounds, hipStream_t st) {
+    if (row1 <= row0) return RRT_OK;
+    const dim3 block(kWGThreads), grid(full_grid.x, (unsigned)(row1 - row0));
+    a.grid_rows = (int)full_grid.y; a.grid_row_base = row0;
     const bool spin = a.spin != 0.0f;
     for (int r = 0; r < rounds; ++r) {
         const bool last = r == rounds - 1;
@@ -1750,8 +1773,84 @@ int launch_deferred(FrameArgs a, bool fast, bool lut, const WorkspaceObject& ws,
         hipLaunchKernelGGL(pool_next_round, dim3(1), dim3(1), 0, st, a.ctr, a.block_capacity, last ? 1 : 0);
         RRT_HIP(hipGetLastError());
     }
-    /* what this launch needed, for the next one's round count (and rrt_workspace_stats) */
-    if (ws.h_stats) RRT_HIP(hipMemcpyAsync(ws.h_stats, ws.d_base, sizeof(DeferCounters), hipMemcpyDeviceToHost, st));
+    return RRT_OK;
+}
+
+/* Three-pass launch through a workspace.  Returns RRT_OK after enqueuing, or -1 if the workspace cannot
+ * hold this launch's bookkeeping plus a useful pool (the caller then uses the single-kernel path).
+ *
+ * TWO CHAINS (round 4).  A rank's share of a frame is a few rounds of wavefronts, and each of the three kernels ends in a
+ * tail: a lone wavefront retires a dependent instruction every ~10 clocks, the SIMDs are only busy with 5-6 of them, so the
+ * last-started waves of the march take a full 1.5 ms whatever else has finished, and the chip decays from full to empty
+ * over that time (profiles/r04_wave_timeline_default.txt: 1.1 of the 5.4 ms of an eighth of the 4K bench frame).  The
+ * launch is therefore cut in two along its dispatch order -- the first half of the dispatch rows (the frame's middle, or the
+ * costliest tiles under rrt_tile_order) and the second -- and each half runs its own march -> evaluate -> composite chain
+ * on its own stream with its own slice of the pool: the evaluation and compositing of one half fill the march tail of the
+ * other.  Same kernels, same arithmetic, same bytes; an eighth of the bench frame 5.7 -> 5.2 ms, of the view from inside
+ * the disk 12.4 -> 9.5 ms (profiles/r04_split_chain_probe.txt).  The side stream and its events belong to the workspace;
+ * a launch that is being captured into a graph, or a small one, runs one chain. */
+int launch_deferred(FrameArgs a, bool fast, bool lut, const WorkspaceObject& ws, int pool_rounds, int chains_wanted, hipStream_t st) {
+    dim3 grid((a.width + kWGPixX - 1) / kWGPixX, (a.rows.n_local_rows + kWGPixY - 1) / kWGPixY);
+    const size_t n_waves = (size_t)grid.x * grid.y * kWGWaves;
+    const size_t n_lanes = n_waves * 64;
+    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t off_hdr = 256;
+    static_assert(kMaxChains * kCounterStride <= 256, "the chains' counters sit in front of the wave headers");
+    const size_t off_fin = align(off_hdr + n_waves * sizeof(WaveHdr));
+    const size_t off_rows = align(off_fin + n_lanes * 4 * kFinalPlanes);
+    if (ws.bytes < off_rows + (size_t)1024 * kBlockBytes) return -1;
+    size_t cap = (ws.bytes - off_rows) / kBlockBytes;
+    if (cap > 0x0fffffffu) cap = 0x0fffffffu;
+    a.hdr = reinterpret_cast<WaveHdr*>(ws.d_base + off_hdr);
+    a.finals = reinterpret_cast<float*>(ws.d_base + off_fin);
+    a.n_lanes = n_lanes;
+    /* one chain or two */
+    int chains = 1;
+    if (chains_wanted != 1 && ws.side != nullptr && grid.y >= 8 && cap >= 4096 && n_waves >= (chains_wanted == 2 ? 2u : 2048u)) {
+        hipStreamCaptureStatus capst = hipStreamCaptureStatusNone;
+        if (st != nullptr && hipStreamIsCapturing(st, &capst) != hipSuccess) { (void)hipGetLastError(); capst = hipStreamCaptureStatusNone; }
+        if (capst == hipStreamCaptureStatusNone) chains = 2;
+    }
+    RRT_HIP(hipMemsetAsync(ws.d_base, 0, off_fin, st));            /* counters + wave headers */
+    /* the pool's split: by what each chain pooled last time (the heavy half holds most of the media), 65 : 35 without history */
+    size_t cap_of[kMaxChains] = {cap, 0};
+    int row_end[kMaxChains] = {(int)grid.y, (int)grid.y};
+    if (chains == 2) {
+        double share = 0.65;
+        const volatile DeferCounters* h = ws.h_stats;
+        if (h && h[0].rounds_run != 0u && h[1].rounds_run != 0u) {
+            const double t0 = (double)h[0].total_blocks, t1 = (double)h[1].total_blocks;
+            if (t0 + t1 > 0.0) share = t0 / (t0 + t1);
+        }
+        share = share < 0.3 ? 0.3 : (share > 0.85 ? 0.85 : share);
+        cap_of[0] = (size_t)((double)cap * share);
+        cap_of[1] = cap - cap_of[0];
+        row_end[0] = (int)grid.y / 2;
+    }
+    if (chains == 2) {            /* fork: the side stream starts behind the memset, BEFORE anything of chain 0 is in the caller's stream */
+        RRT_HIP(hipEventRecord(ws.forked, st));
+        RRT_HIP(hipStreamWaitEvent(ws.side, ws.forked, 0));
+    }
+    size_t block0 = 0;
+    int row0 = 0;
+    for (int c = 0; c < chains; ++c) {
+        FrameArgs b = a;
+        b.ctr = reinterpret_cast<DeferCounters*>(ws.d_base + (size_t)c * kCounterStride);
+        b.sample_blocks = ws.d_base + off_rows + block0 * kBlockBytes;
+        b.block_capacity = (unsigned)cap_of[c];
+        const int rounds = pool_rounds > 0 ? pool_rounds : auto_pool_rounds(ws.h_stats ? ws.h_stats + c : nullptr, b.block_capacity);
+        const hipStream_t cs = c == 1 ? ws.side : st;
+        const int rc = enqueue_chain(b, fast, lut, grid, row0, row_end[c], rounds, cs);
+        if (rc != RRT_OK) return rc;
+        /* what this chain needed, for the next launch's round count and pool split (and rrt_workspace_stats) */
+        if (ws.h_stats) RRT_HIP(hipMemcpyAsync(ws.h_stats + c, b.ctr, sizeof(DeferCounters), hipMemcpyDeviceToHost, cs));
+        if (c == 1) {                                          /* join */
+            RRT_HIP(hipEventRecord(ws.joined, ws.side));
+            RRT_HIP(hipStreamWaitEvent(st, ws.joined, 0));
+        }
+        block0 += cap_of[c]; row0 = row_end[c];
+    }
+    if (chains == 1 && ws.h_stats) memset(const_cast<DeferCounters*>(ws.h_stats) + 1, 0, sizeof(DeferCounters));   /* no second chain this time */
     return RRT_OK;
 }
 
@@ -1796,6 +1895,7 @@ int enqueue_probe(const FrameArgs& a, ProbeArgs& q, unsigned* cells, int stride_
     q.cells_x = (a.width + stride_x - 1) / stride_x;
     q.cells_y = (a.rows.n_local_rows + stride_y - 1) / stride_y;
     q.w_step = RRT_PROBE_W_STEP; q.w_acc = RRT_PROBE_W_ACC; q.w_dust = RRT_PROBE_W_DUST;
+    q.ring_steps = (float)a.max_steps;
     if (const char* e = getenv("RRT_PROBE_WEIGHTS")) {          /* dev: tools/probe_fit.py reads the three counts one at a time */
         float w0, w1, w2;
         if (sscanf(e, "%f,%f,%f", &w0, &w1, &w2) == 3) { q.w_step = w0; q.w_acc = w1; q.w_dust = w2; }
@@ -1871,7 +1971,7 @@ int launch(const FrameArgs& a, const LaunchOpts& o, bool debug, hipStream_t st) 
     }
     bool launched = false;
     if (deferred) {
-        const int rc = launch_deferred(b, o.fast, o.media == 2, ws, o.pool_rounds, st);
+        const int rc = launch_deferred(b, o.fast, o.media == 2, ws, o.pool_rounds, o.pass_chains, st);
         if (rc > 0) return rc;
         launched = rc == RRT_OK;
     }
@@ -2024,12 +2124,23 @@ int rrt_sky_destroy(rrt_sky_t sky) {
 
 int rrt_workspace_create(size_t bytes, int* out) {
     if (!out || bytes < (size_t)1 << 20) return RRT_ERR_INVALID_ARGUMENT;
-    WorkspaceObject w{nullptr, bytes, current_device(), nullptr};
+    WorkspaceObject w{nullptr, bytes, current_device(), nullptr, nullptr, nullptr, nullptr};
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&w.d_base), bytes);
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(workspace)");
-    e = hipHostMalloc(reinterpret_cast<void**>(&w.h_stats), sizeof(DeferCounters), hipHostMallocDefault);
+    e = hipHostMalloc(reinterpret_cast<void**>(&w.h_stats), kMaxChains * sizeof(DeferCounters), hipHostMallocDefault);
     if (e != hipSuccess) { (void)hipFree(w.d_base); return hip_fail(e, "hipHostMalloc(workspace statistics)"); }
-    memset(w.h_stats, 0, sizeof(DeferCounters));
+    memset(w.h_stats, 0, kMaxChains * sizeof(DeferCounters));
+    /* the second chain's stream and the fork / join events; without them launches run one chain.  Default priority on
+     * purpose: a higher-priority stream is served STRICTLY first on this hardware -- the other queue did not start until the
+     * whole high-priority chain had finished (kernel trace, profiles/README.md round 4): serial again, and slower */
+    if (hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&w.forked, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&w.joined, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (w.side) (void)hipStreamDestroy(w.side);
+        if (w.forked) (void)hipEventDestroy(w.forked);
+        w.side = nullptr; w.forked = nullptr; w.joined = nullptr;
+    }
     std::lock_guard<std::mutex> lk(g_ws_mu);
     *out = g_ws_next++;
     g_ws.emplace(*out, w);
@@ -2168,12 +2279,26 @@ int rrt_workspace_destroy(int id) {
         w = it->second;
         g_ws.erase(it);
     }
+    if (w.side) { (void)hipStreamSynchronize(w.side); (void)hipStreamDestroy(w.side); }
+    if (w.forked) (void)hipEventDestroy(w.forked);
+    if (w.joined) (void)hipEventDestroy(w.joined);
     hipError_t e = hipFree(w.d_base);
     if (w.h_stats) (void)hipHostFree(w.h_stats);
     if (e != hipSuccess) return hip_fail(e, "hipFree(workspace)");
     return RRT_OK;
 }
 
+}  // extern "C"
+namespace {
+hipError_t read_chain_counters(const WorkspaceObject& w, DeferCounters* out) {
+    uint8_t raw[kMaxChains * kCounterStride];
+    const hipError_t e = hipMemcpy(raw, w.d_base, sizeof(raw), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return e;
+    for (int k = 0; k < kMaxChains; ++k) memcpy(&out[k], raw + (size_t)k * kCounterStride, sizeof(DeferCounters));
+    return hipSuccess;
+}
+}  // namespace
+extern "C" {
 int rrt_workspace_stats(int id, unsigned* rows_used, unsigned* overflow_waves) {
     WorkspaceObject w;
     {
@@ -2183,11 +2308,12 @@ int rrt_workspace_stats(int id, unsigned* rows_used, unsigned* overflow_waves) {
         w = it->second;
     }
     if (!on_current_device(w.device)) return RRT_ERR_BAD_HANDLE;
-    DeferCounters c;
-    RRT_HIP(hipMemcpy(&c, w.d_base, sizeof(c), hipMemcpyDeviceToHost));
-    const unsigned long long rows = c.total_blocks * kBlockRows;
+    DeferCounters c[kMaxChains];
+    RRT_HIP(read_chain_counters(w, c));
+    unsigned long long rows = 0; unsigned left = 0;
+    for (int k = 0; k < kMaxChains; ++k) { rows += c[k].total_blocks * kBlockRows; left += c[k].suspended_left; }
     if (rows_used) *rows_used = rows > 0xffffffffull ? 0xffffffffu : (unsigned)rows;
-    if (overflow_waves) *overflow_waves = c.suspended_left;
+    if (overflow_waves) *overflow_waves = left;
     return RRT_OK;
 }
 
@@ -2200,11 +2326,17 @@ int rrt_workspace_rounds(int id, unsigned* rounds_enqueued, unsigned* rounds_wit
         w = it->second;
     }
     if (!on_current_device(w.device)) return RRT_ERR_BAD_HANDLE;
-    DeferCounters c;
-    RRT_HIP(hipMemcpy(&c, w.d_base, sizeof(c), hipMemcpyDeviceToHost));
-    if (rounds_enqueued) *rounds_enqueued = c.rounds_run;
-    if (rounds_with_work) *rounds_with_work = c.rounds_with_work;
-    if (peak_rows) *peak_rows = c.peak_blocks * kBlockRows;
+    DeferCounters c[kMaxChains];
+    RRT_HIP(read_chain_counters(w, c));
+    unsigned run = 0, work = 0, peak = 0;
+    for (int k = 0; k < kMaxChains; ++k) {        /* rounds: of the chain that needed most; rows of the fullest round: both chains' */
+        run = c[k].rounds_run > run ? c[k].rounds_run : run;
+        work = c[k].rounds_with_work > work ? c[k].rounds_with_work : work;
+        peak += c[k].peak_blocks;
+    }
+    if (rounds_enqueued) *rounds_enqueued = run;
+    if (rounds_with_work) *rounds_with_work = work;
+    if (peak_rows) *peak_rows = peak * kBlockRows;
     if (pool_rows) *pool_rows = (unsigned)((w.bytes / kBlockBytes) * kBlockRows);      /* upper bound: before the launch's bookkeeping */
     return RRT_OK;
 }

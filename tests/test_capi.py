@@ -174,7 +174,7 @@ def test_struct_layouts_match_the_reference_structs():
     assert [offs[k] for k in ("use_bloom", "bloom_threshold", "bloom_intensity", "use_vignette",
                               "vignette_intensity", "use_chromatic_aberration", "ca_amount",
                               "use_lens_distortion", "distortion_amount")] == [0, 4, 8, 12, 16, 20, 24, 28, 32]
-    assert C.sizeof(_lib.rrt_params) == 44          # ABI 4: struct_size first, pool_rounds last
+    assert C.sizeof(_lib.rrt_params) == 48          # ABI 4: struct_size first, pool_rounds / pass_chains last
     assert _lib.rrt_params.struct_size.offset == 0 and _lib.rrt_params.spin.offset == 4
 
 
@@ -244,7 +244,7 @@ def test_params_from_another_abi_are_refused_not_believed():
     from relativisticraytracer_amd import _lib
     lib = _lib.load()
     prm = _lib.rrt_params()
-    assert lib.rrt_params_default_v4(C.byref(prm)) == 0 and prm.struct_size == 44 and prm.pool_rounds == 0
+    assert lib.rrt_params_default_v4(C.byref(prm)) == 0 and prm.struct_size == 48 and prm.pool_rounds == 0 and prm.pass_chains == 0
     assert lib.rrt_set_launch_defaults(C.byref(prm)) == 0
     prm.struct_size = 36
     assert lib.rrt_set_launch_defaults(C.byref(prm)) == 6           # RRT_ERR_ABI_MISMATCH
@@ -259,7 +259,7 @@ def test_params_from_another_abi_are_refused_not_believed():
     # ... and what it wrote is refused as an ABI-4 struct (first word = spin bits = 0, not a size)
     old = (C.c_uint8 * 64).from_buffer_copy(buf.tobytes())
     assert lib.rrt_set_launch_defaults(C.cast(old, C.POINTER(_lib.rrt_params))) == 6
-    prm.struct_size = 44; prm.pool_rounds = -1
+    prm.struct_size = 48; prm.pool_rounds = -1
     assert lib.rrt_set_launch_defaults(C.byref(prm)) == 1
 
 

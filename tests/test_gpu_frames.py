@@ -501,7 +501,7 @@ def test_three_pass_full_size_and_heavy_view(ctx):
             rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9))
             out = torch.zeros_like(ref)
             rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, workspace=pool.id, path_policy=2,
-                                                                             pool_rounds=1 if pool is small else 0))
+                                                                             pool_rounds=1 if pool is small else 8))        # small: ONE round -> the in-line route; big: rounds to spare
             torch.cuda.synchronize()
             st = pool.stats()
             assert torch.equal(out, ref), (w, h, st)
@@ -528,7 +528,7 @@ def test_three_pass_rounds_reuse_a_small_pool(ctx):
     import torch
     g, rrt, tex = ctx
     fx = rrt.CameraEffects(useChromaticAberration=True)
-    pool = rrt.Workspace(40 << 20)
+    pool = rrt.Workspace(30 << 20)
     nt = rrt.NoiseTable(16.0)
     order = rrt.TileOrder()
     try:
@@ -541,22 +541,26 @@ def test_three_pass_rounds_reuse_a_small_pool(ctx):
                 if mode:
                     rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=spin, arith_mode=1))
                 seen = []
-                for rounds, table, oid in ((48, 0, 0), (48, nt.id, 0), (2, 0, 0), (1, nt.id, 0), (48, nt.id, order.id), (48, 0, order.id)):
+                for rounds, table, oid, chains in ((48, 0, 0, 1), (48, nt.id, 0, 1), (2, 0, 0, 1), (1, nt.id, 0, 1), (48, nt.id, order.id, 1),
+                                                   (48, 0, order.id, 1), (48, nt.id, 0, 2), (48, 0, order.id, 2), (1, nt.id, order.id, 2)):
                     out = torch.zeros_like(ref)
                     rrt.launch_raymarch(out, w, h, t, cam, tex, fx,
                                         rrt.RenderParams(spin=spin, arith_mode=mode, workspace=pool.id, path_policy=2,
-                                                         pool_rounds=rounds, noise_table=table, tile_order=oid))
+                                                         pool_rounds=rounds, noise_table=table, tile_order=oid, pass_chains=chains))
                     torch.cuda.synchronize()
                     st = pool.stats()
                     assert torch.equal(out, ref), (w, h, mode, rounds, st)
                     assert st["rounds_enqueued"] == rounds
                     seen.append(st)
-                assert seen[0]["overflow_waves"] == 0 and seen[0]["rounds_with_work"] >= 3, seen[0]
+                assert seen[0]["overflow_waves"] == 0 and seen[0]["rounds_with_work"] >= 2, seen[0]
                 assert seen[0]["peak_rows"] <= seen[0]["pool_rows"] and seen[0]["rows_used"] > seen[0]["pool_rows"]
                 assert seen[2]["overflow_waves"] > 0 and seen[3]["overflow_waves"] > 0        # too few rounds: in line
                 assert seen[4]["overflow_waves"] == 0 and seen[5]["overflow_waves"] == 0
+                # two chains (each half of the dispatch order in its own slice of the pool, on its own stream): same bytes,
+                # nothing in line with enough rounds, the in-line route with one
+                assert seen[6]["overflow_waves"] == 0 and seen[7]["overflow_waves"] == 0 and seen[8]["overflow_waves"] > 0
         # automatic: the first launch through a fresh workspace guesses 2 rounds, later ones take what the previous one needed
-        fresh = rrt.Workspace(40 << 20)
+        fresh = rrt.Workspace(30 << 20)
         w, h, t = 320, 180, 14.0
         cam = rrt.CameraState.from_angles((4.2, 0.6, 4.2), -90.0, -5.7)
         ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
@@ -573,6 +577,48 @@ def test_three_pass_rounds_reuse_a_small_pool(ctx):
         fresh.destroy()
     finally:
         pool.destroy(); nt.destroy(); order.destroy()
+
+
+def test_three_pass_two_chains_by_default_on_larger_launches(ctx):
+    """rrt_params.pass_chains = 0: a launch of >= 2048 wavefronts runs its two halves as two chains side by side -- bytes of
+    the single kernel for full frames and shards, repeatedly through one workspace (the pool split and the round counts adapt
+    to what the previous launch needed), also with a pool small enough to need rounds in the heavy half."""
+    import torch
+    g, rrt, tex = ctx
+    fx = rrt.CameraEffects()
+    nt = rrt.NoiseTable(16.0)
+    try:
+        for (w, h, pos, yaw, pitch, t, pool_mib) in ((960, 540, (0.0, 10.0, -60.0), 0.0, -10.0, 1.0, 512),
+                                                     (640, 360, (4.2, 0.6, 4.2), -90.0, -5.7, 14.0, 96)):
+            cam = rrt.CameraState.from_angles(pos, yaw, pitch)
+            ws = rrt.Workspace(pool_mib << 20)
+            ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+            rrt.launch_raymarch(ref, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id))
+            prm = rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=ws.id, path_policy=2)
+            hist = []
+            for k in range(8):          # the round count doubles (+1) while rays are still suspended at the end: it converges
+                out = torch.zeros_like(ref)
+                rrt.launch_raymarch(out, w, h, t, cam, tex, fx, prm)
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref), (w, h, k, ws.stats())
+                hist.append(ws.stats())
+            assert hist[-1]["overflow_waves"] == 0 and hist[-2]["overflow_waves"] == 0, hist
+            one = rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=ws.id, path_policy=2, pass_chains=1)
+            out = torch.zeros_like(ref)
+            rrt.launch_raymarch(out, w, h, t, cam, tex, fx, one)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+            # shards (interleaved tiles) through two chains, two launches back to back on one stream through one workspace
+            frame = torch.zeros_like(ref)
+            for sh in range(2):
+                buf = torch.zeros(rrt.tile_shard_rows(h, 16, sh, 2) * w * 4, dtype=torch.uint8, device="cuda")
+                rrt.launch_raymarch_tiles(buf, w, h, 16, sh, 2, t, cam, tex, fx, prm)
+                rrt.assemble_tiles(frame, buf, w, h, 16, sh, 2)
+            torch.cuda.synchronize()
+            assert torch.equal(frame, ref)
+            ws.destroy()
+    finally:
+        nt.destroy()
 
 
 def test_tile_maps_probe_and_balance(ctx):

@@ -1,10 +1,9 @@
 """dev tool (GPU): single-GPU projection of an N-way split of a 4K frame -- every shard rendered alone on this GPU
 through the path a rank takes (three-pass pool, noise tables), timed with device events; MAX over the shards is what a
 frame would take on N GPUs (gather / assemble excluded).  Compares tile -> shard assignments and dispatch orders:
-  modulo          tile t -> shard t mod N (rounds 1-3)
+  t mod N         tile t -> shard t mod N (rounds 1-3), with one chain (round 3's path) and with two (round 4)
   probe           rrt_probe_tile_costs + rrt_tile_map_balance (what a first frame can know)
-  measured        the tiles' MEASURED costs (rrt_tile_order clocks of the modulo run, summed per row tile), dealt the same way
-each in the static dispatch order and with rrt_tile_order (second launch: ordered by the first one's costs).
+  measured        the tiles' MEASURED costs (rrt_tile_order clocks of the one-chain run, summed per row tile), dealt the same way
     python tools/shard_maps.py [view] [N] [pool MiB] [spin]      -> profiles/r04_shard_kernel_times_<view>.txt"""
 import os, sys
 import numpy as np
@@ -39,38 +38,47 @@ def timed(fn, reps=3):
 full = timed(lambda: rrt.launch_raymarch(buf, W, H, t, cam, tex, fx, rrt.RenderParams(spin=spin, noise_table=nt.id)))
 print(f"# {view} 4K a={spin:g}, {N} shards of {R}-row tiles, three-pass through a {pool_mib} MiB pool, noise tables; single-GPU frame (single kernel) {full:.3f} ms")
 
-def run(assignment, ordered, collect=None):
+def run(assignment, chains, collect=None, ordered=False):
+    """every shard of `assignment` alone on this GPU; chains: rrt_params.pass_chains.  collect: also record the tiles' measured
+    costs (one extra launch per shard through an rrt_tile_order object, seeding off).  ordered: time the launches through a
+    tile-order object in its steady state (each dispatched by the previous one's measured costs)."""
     tm = rrt.TileMap(H, R, N, assignment)
     times, stats = [], []
     for sh in range(N):
-        order = rrt.TileOrder() if (ordered or collect is not None) else None
-        if order is not None and not ordered:
-            order.set_seeding(False)
-        prm = rrt.RenderParams(spin=spin, noise_table=nt.id, workspace=ws.id, path_policy=2, tile_order=order.id if order else 0)
+        order = rrt.TileOrder() if ordered else None
+        prm = rrt.RenderParams(spin=spin, noise_table=nt.id, workspace=ws.id, path_policy=2, pass_chains=chains, tile_order=order.id if order else 0)
         times.append(timed(lambda: rrt.launch_raymarch_tilemap(buf, W, H, tm, sh, t, cam, tex, fx, prm)))
         stats.append(ws.stats())
+        if order is not None:
+            order.destroy()
         if collect is not None:
-            info = order.info(arrays=True)
+            o2 = rrt.TileOrder(); o2.set_seeding(False)
+            p2 = rrt.RenderParams(spin=spin, noise_table=nt.id, workspace=ws.id, path_policy=2, pass_chains=1, tile_order=o2.id)
+            rrt.launch_raymarch_tilemap(buf, W, H, tm, sh, t, cam, tex, fx, p2); torch.cuda.synchronize()
+            info = o2.info(arrays=True)
             rows = tm.shard_rows(sh)
             c = info["cost"].astype(np.float64).reshape(rows // 8, W // 8)
             mine = [tt for tt in range(n_tiles) if assignment[tt] == sh]
             per_tile = c.reshape(len(mine), R // 8, W // 8).sum(axis=(1, 2))
             for k, tt in enumerate(mine):
                 collect[tt] = per_tile[k]
-        if order is not None:
-            order.destroy()
+            o2.destroy()
     tm.destroy()
     return times, stats
 
 modulo = (np.arange(n_tiles) % N).astype(np.int32)
 measured = np.zeros(n_tiles)
-base_t, base_s = run(modulo, False, collect=measured)
+one_t, one_s = run(modulo, 1, collect=measured)
 probe = rrt.probe_tile_costs(W, H, R, t, cam, fx, rrt.RenderParams(spin=spin))
-maps = {"modulo": modulo, "probe": rrt.balance_tiles(probe, N), "measured": rrt.balance_tiles(measured.astype(np.float32), N)}
-for name, m in maps.items():
-    for ordered in (False, True):
-        ts, st = (base_t, base_s) if (name == "modulo" and not ordered) else run(m, ordered)
-        cnt = np.bincount(m, minlength=N)
-        print(f"{name:9s} {'cost-ordered' if ordered else 'static order'}: max shard {max(ts):.3f} ms  min {min(ts):.3f}  mean {np.mean(ts):.3f}  "
-              f"balance min/max {min(ts) / max(ts):.3f}  -> {full / max(ts):.2f}x of the single-GPU frame;  tiles per shard {cnt.min()}-{cnt.max()}, "
-              f"rounds with work {max(s['rounds_with_work'] for s in st)}, in-line fall-backs {sum(s['overflow_waves'] for s in st)}", flush=True)
+cases = [("t mod N, one chain (round 3's path)", modulo, 1, False, (one_t, one_s)),
+         ("t mod N, two chains", modulo, 0, False, None),
+         ("t mod N, two chains, cost-ordered dispatch", modulo, 0, True, None),
+         ("dealt by the probe's estimate, two chains", rrt.balance_tiles(probe, N), 0, False, None),
+         ("dealt by measured costs, two chains", rrt.balance_tiles(measured.astype(np.float32), N), 0, False, None)]
+for name, m, chains, ordered, done in cases:
+    ts, st = done if done else run(m, chains, ordered=ordered)
+    cnt = np.bincount(m, minlength=N)
+    print(f"{name:44s}: max shard {max(ts):.3f} ms  min {min(ts):.3f}  mean {np.mean(ts):.3f}  balance min/max {min(ts) / max(ts):.3f}  "
+          f"-> {full / max(ts):.2f}x of the single-GPU frame;  tiles per shard {cnt.min()}-{cnt.max()}, rounds with work "
+          f"{max(s['rounds_with_work'] for s in st)}, in-line fall-backs {sum(s['overflow_waves'] for s in st)}", flush=True)
+    print("    per shard [ms]: " + " ".join(f"{v:.3f}" for v in ts), flush=True)
