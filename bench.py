@@ -412,7 +412,28 @@ def main():
             hms = (time.perf_counter() - t1) / max(2, args.steps // 2) * 1e3
             res[tag] = {"ms_per_step": round(hms, 3), "Mrays_per_s": round(w * h / hms / 1e3, 3), "fps": round(1e3 / hms, 3)}
         horder.destroy()
+        # the FIRST frame of that view (a still image, frame 1 of a sequence): an rrt_tile_order object without history takes
+        # its order from a coarse march-only probe of the view itself (one ray per 16x16 pixels, probe + sort inside the time);
+        # the object's buffers are sized beforehand by a launch of another geometry, as a host that reuses one object would
+        if ntab:
+            firsts = []
+            for _ in range(3):
+                fo = rrt.TileOrder()
+                hp = rrt.RenderParams(spin=args.spin, volumetrics=1, noise_table=ntab.id, tile_order=fo.id)
+                big = torch.zeros((h + 8) * w * 4, dtype=torch.uint8, device=dev)
+                rrt.launch_raymarch(big, w, h + 8, ht, hcam, tex, fx, hp)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); rrt.launch_raymarch(hbuf, w, h, ht, hcam, tex, fx, hp); e1.record()
+                torch.cuda.synchronize()
+                firsts.append(e0.elapsed_time(e1))
+                fo.destroy(); del big
+            res["noise_table_first_frame_probe_ordered"] = {"ms_per_step": round(min(firsts), 3), "Mrays_per_s": round(w * h / min(firsts) / 1e3, 3),
+                                                            "fps": round(1e3 / min(firsts), 3)}
         heavy = {"view": "Horizon Skimmer key (4.2, 0.6, 4.2) yaw -90 pitch -5.7, t=14.0, same size / spin / effects", **res}
+        if "noise_table_first_frame_probe_ordered" in heavy:
+            heavy["noise_table_first_frame_probe_ordered"]["note"] = ("first launch through a fresh rrt_tile_order object: order from the coarse probe of "
+                                                                      "the view (probe + sort inside the time); same bytes")
         if "noise_table_cost_ordered" in heavy:
             heavy["noise_table_cost_ordered"]["note"] = ("rrt_params.tile_order: wave tiles dispatched longest-first, costs measured by the previous "
                                                          "launch (the sort behind every frame is inside the time); same bytes")
@@ -459,7 +480,7 @@ def main():
                                  time_=14.0)
             heavy["per_ray_means"] = {k: round(v, 2) for k, v in hm.items()}
             heavy["ops_per_ray"] = round(ops_per_ray(hm["steps"], hm["n_noise"], hm["n_dens"], hm["n_samples"]), 1)
-            for tag in ("arithmetic_noise", "noise_table", "noise_table_cost_ordered"):
+            for tag in ("arithmetic_noise", "noise_table", "noise_table_cost_ordered", "noise_table_first_frame_probe_ordered"):
                 if tag in heavy:
                     heavy[tag]["valu_roofline_frac"] = round(heavy["ops_per_ray"] * rays / (heavy[tag]["ms_per_step"] * 1e-3) / 1e12
                                                              / VALU_PEAK_TOPS, 4)

@@ -360,13 +360,20 @@ int rrt_unit_media_lut(int n, const float* d_p, float time, int table, float* d_
  * [0] receives the number of mismatching cases, [1..3] one failing case. */
 int rrt_selfcheck_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* stream);
 int rrt_selfcheck_div(unsigned long long n_cases, uint32_t seed, unsigned long long* d_counters, void* stream);
-/* the same two divides with reciprocal-root seeds as the march itself produces them: out of sqrt_seeded_yh<1> / <2>
- * started from estimates off by up to each form's acceptance tolerance (extrapolated seeds included); rejected roots are
- * skipped; d_counters[3] receives the number of divides checked */
-int rrt_selfcheck_div_march(unsigned long long n_cases, uint32_t seed, unsigned long long* d_counters, void* stream);
+/* the march's seeded roots and the same two divides with the reciprocal-root seeds those roots hand on: roots out of
+ * sqrt_seeded_yh<1> / <2> started from estimates off by up to +-tol1 / +-tol2 relative (the forms' acceptance tolerances are
+ * 1.5e-4 / 9e-3; extrapolated seeds included); rejected roots are skipped.  d_counters: EIGHT uint64 -- [0] / [1] accepted
+ * one- / two-iteration roots that are not the correctly rounded root, [2] divide mismatches, [3] divides checked, [4..7] one
+ * failing root (x, seed bits) and one failing divide (numerator, denominator bits) */
+int rrt_selfcheck_div_march(unsigned long long n_cases, uint32_t seed, float tol1, float tol2, unsigned long long* d_counters, void* stream);
 /* the march's transcendental-free square root (csrc/rrt_device.h: sqrt_seeded) over a range of float bit patterns
  * and a ladder of seed errors; d_counters[3] receives the number of accepted (checked) cases */
 int rrt_selfcheck_sqrt_seeded(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* stream);
+/* the seeded roots on the floats within `span` ulps of every power of two 2^e, e in [e_lo, e_hi) -- where sqrt(x) comes closest
+ * to a rounding tie -- under a dense sweep of n_seeds seeds per x and form over +-tol1 / +-tol2.  d_counters: SIX uint64 -- [0] / [1]
+ * accepted one- / two-iteration roots that differ from sqrtf, [2] accepted roots checked, [3] rejected, [4]/[5] one failing case */
+int rrt_selfcheck_sqrt_boundaries(int e_lo, int e_hi, int span, unsigned n_seeds, float tol1, float tol2,
+                                  unsigned long long* d_counters, void* stream);
 /* the media code's three-instruction division by a compile-time constant (csrc/rrt_device.h: rrt_div_const): every
  * dividend with bits in [lo_bits, hi_bits), both signs, for each constant the media code divides by */
 int rrt_selfcheck_div_const(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* stream);

@@ -120,7 +120,8 @@ SYMBOLS = [
     ("rrt_unit_media_lut", _i, [_i, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     ("rrt_selfcheck_sqrt", _i, [C.c_uint32, C.c_uint32, _vp, _vp]),
     ("rrt_selfcheck_div", _i, [_ull, C.c_uint32, _vp, _vp]),
-    ("rrt_selfcheck_div_march", _i, [_ull, C.c_uint32, _vp, _vp]),
+    ("rrt_selfcheck_div_march", _i, [_ull, C.c_uint32, _f, _f, _vp, _vp]),
+    ("rrt_selfcheck_sqrt_boundaries", _i, [_i, _i, _i, C.c_uint, _f, _f, _vp, _vp]),
     ("rrt_selfcheck_div_tame", _i, [_ull, C.c_uint32, _vp, _vp]),
     ("rrt_selfcheck_div_const", _i, [C.c_uint32, C.c_uint32, _vp, _vp]),
     ("rrt_selfcheck_sqrt_seeded", _i, [C.c_uint32, C.c_uint32, _vp, _vp]),

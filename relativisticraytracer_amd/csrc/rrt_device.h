@@ -518,7 +518,19 @@ RRT_DEV bool sqrt_seeded_yh(float x, float y0, float h0, float& root, float& y, 
     root = __builtin_fmaf(d, h, g);
     y = h + h;
     h_out = h;
-    return !(fabsf(first) <= (ITERS == 2 ? kSeedTol2 : kSeedTol));
+    bool rejected = !(fabsf(first) <= (ITERS == 2 ? kSeedTol2 : kSeedTol));
+    if (ITERS == 2) {
+        /* Round 4: the one operand class on which an ACCEPTED two-iteration root was not the correctly rounded one --
+         * x = 4^k (1 + 2^-23), the float right above a power of four, whose root 2^k (1 + 2^-24 - 2^-49) lies 2^-26 ulp under a
+         * rounding tie: the half-reciprocal of the second iteration sits at a binade boundary there and can come out two
+         * of the finer ulps high, which tips g + d h over the tie (rrt_selfcheck_div_march: 176 of 1.1e12 roots with seed
+         * errors spread over the acceptance interval, every one of this form; none among the one-iteration roots, none
+         * after this guard: profiles/r04_div_march_seeds_probe.txt).  Two instructions on the two roots of a GENERIC step
+         * (the vacuum step has one-iteration roots only): such an x takes the v_rsq fall-back, which is checked for every
+         * float. */
+        rejected = rejected || (rrt_f2u(x) & 0x00ffffffu) == 0x00800001u;
+    }
+    return rejected;
 }
 
 /* the v_rsq fall-back of a rejected root, with the `r < 1` case of geodesic_acc(); `small` = geodesics.h:33 fires */

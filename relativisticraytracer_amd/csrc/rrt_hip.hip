@@ -1498,12 +1498,14 @@ __global__ void k_selfcheck_div(unsigned long long n, uint32_t seed, unsigned lo
  * +-1.45e-4 for the one-iteration root -- which also covers the linearly extrapolated seeds of the vacuum step --, +-8.9e-3
  * for the two-iteration one), not out of the v_rsq-based sqrt_rsq that k_selfcheck_div uses: such a y carries up to 1.5 e^2 =
  * 3.4e-8 of its own error into y^3 and y^5, i.e. the Markstein cores start from a seed ~1.7x worse than k_selfcheck_div's.
- * Rejected roots are skipped (the march takes the sqrt_rsq fall-back there).  counters[0] += mismatches, [1]/[2] one failing
- * case (numerator, denominator bits), [3] += checked divides. */
-__global__ void k_selfcheck_div_march(unsigned long long n, uint32_t seed, unsigned long long* counters) {
+ * Rejected roots are skipped (the march takes the sqrt_rsq fall-back there).  The seeded ROOT is checked first (against
+ * the v_rsq-based correctly rounded one): counters (8 x uint64) [0] += accepted one-iteration roots that are not correctly
+ * rounded, [1] += two-iteration ones, [2] += divide mismatches, [3] += divides checked, [4]/[5] one failing root (x bits,
+ * seed bits), [6]/[7] one failing divide (numerator, denominator bits).  tol1 / tol2: half-width of the seed errors tried. */
+__global__ void k_selfcheck_div_march(unsigned long long n, uint32_t seed, float tol1, float tol2, unsigned long long* counters) {
     uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned bad = 0;
+    unsigned bad_root1 = 0, bad_root2 = 0, bad_div = 0;
     unsigned long long checked = 0;
     for (uint64_t k = idx; k < n; k += stride) {
         uint32_t h1 = mix32((uint32_t)k * 2654435761u + seed), h2 = mix32(h1 ^ (uint32_t)(k >> 32) ^ 0x9e3779b9u);
@@ -1515,20 +1517,26 @@ __global__ void k_selfcheck_div_march(unsigned long long n, uint32_t seed, unsig
         sqrt_rsq(r2, r_ref, y_ref);
         const bool two = (h4 & 1u) != 0;
         const float u = (float)((h4 >> 8) & 0xffffffu) * (2.0f / 16777216.0f) - 1.0f;      /* [-1, 1) */
-        const float y0 = y_ref * (1.0f + u * (two ? 8.9e-3f : 1.45e-4f));
+        const float y0 = y_ref * (1.0f + u * (two ? tol2 : tol1));
         float r, y, hy;
         const bool rejected = two ? sqrt_seeded_yh<2>(r2, y0, 0.5f * y0, r, y, hy) : sqrt_seeded_yh<1>(r2, y0, 0.5f * y0, r, y, hy);
         if (rejected) continue;
-        if (rrt_f2u(r) != rrt_f2u(r_ref)) { ++bad; counters[1] = rrt_f2u(r2); counters[2] = rrt_f2u(y0); continue; }
+        if (rrt_f2u(r) != rrt_f2u(r_ref)) {            /* an ACCEPTED root that is not the correctly rounded one */
+            if (two) ++bad_root2; else ++bad_root1;
+            counters[4] = rrt_f2u(r2); counters[5] = rrt_f2u(y0);
+            continue;
+        }
         float y2 = y * y, y3 = y2 * y;
         float d2 = r2 * r, d1 = (r2 * r2) * r;
         float q1 = div_seeded(num, d1, y3 * y2), q2 = div_seeded(c, d2, y3);
         float w1 = num / d1, w2 = c / d2;
         checked += 2;
-        if (rrt_f2u(q1) != rrt_f2u(w1)) { ++bad; counters[1] = rrt_f2u(num); counters[2] = rrt_f2u(d1); }
-        if (rrt_f2u(q2) != rrt_f2u(w2)) { ++bad; counters[1] = rrt_f2u(c); counters[2] = rrt_f2u(d2); }
+        if (rrt_f2u(q1) != rrt_f2u(w1)) { ++bad_div; counters[6] = rrt_f2u(num); counters[7] = rrt_f2u(d1); }
+        if (rrt_f2u(q2) != rrt_f2u(w2)) { ++bad_div; counters[6] = rrt_f2u(c); counters[7] = rrt_f2u(d2); }
     }
-    if (bad) atomicAdd(counters, (unsigned long long)bad);
+    if (bad_root1) atomicAdd(counters, (unsigned long long)bad_root1);
+    if (bad_root2) atomicAdd(counters + 1, (unsigned long long)bad_root2);
+    if (bad_div) atomicAdd(counters + 2, (unsigned long long)bad_div);
     atomicAdd(counters + 3, checked);
 }
 
@@ -1575,6 +1583,44 @@ __global__ void k_selfcheck_sqrt_seeded(uint32_t lo, uint32_t hi, unsigned long 
     }
     if (bad) atomicAdd(counters, (unsigned long long)bad);
     atomicAdd(counters + 3, accepted);
+}
+
+/* The seeded roots on the floats AROUND every power of two (x = 2^e (1 + j 2^-23), |j| <= span, e in [e_lo, e_hi)) under a DENSE
+ * sweep of seeds: n_seeds estimates per x and form, spread evenly over +-tol1 (one iteration) / +-tol2 (two).  That is where
+ * sqrt(x) comes closest to a rounding tie (x = 4^k (1 + 2^-23): 2^-26 ulp) and where round 4 found -- and guarded -- the one
+ * class of accepted roots that were not correctly rounded.  counters: [0] / [1] mismatching accepted one- / two-iteration
+ * roots, [2] accepted roots checked, [3] rejected ones, [4]/[5] one failing case (x bits, seed bits). */
+__global__ void k_selfcheck_sqrt_boundaries(int e_lo, int e_hi, int span, unsigned n_seeds, float tol1, float tol2,
+                                            unsigned long long* counters) {
+    const uint64_t n_x = (uint64_t)(e_hi - e_lo) * (2 * span + 1);
+    const uint64_t total = n_x * n_seeds;
+    unsigned bad1 = 0, bad2 = 0;
+    unsigned long long ok = 0, rej = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t xi = i / n_seeds;
+        const unsigned si = (unsigned)(i - xi * n_seeds);
+        const int e = e_lo + (int)(xi / (2 * span + 1)), j = (int)(xi % (2 * span + 1)) - span;
+        const uint32_t bits = (uint32_t)((e + 127) << 23) + (uint32_t)j;          /* j < 0 reaches into the binade below */
+        const float x = rrt_u2f(bits);
+        float r_ref, y_ref;
+        sqrt_rsq(x, r_ref, y_ref);
+        const float want = sqrtf(x);
+        const float u = ((float)si + 0.5f) * (2.0f / (float)n_seeds) - 1.0f;     /* (-1, 1) */
+        float r, y, hy;
+        const float s1 = y_ref * (1.0f + u * tol1), s2 = y_ref * (1.0f + u * tol2);
+        if (!sqrt_seeded_yh<1>(x, s1, 0.5f * s1, r, y, hy)) {
+            ++ok;
+            if (rrt_f2u(r) != rrt_f2u(want)) { ++bad1; counters[4] = bits; counters[5] = rrt_f2u(s1); }
+        } else ++rej;
+        if (!sqrt_seeded_yh<2>(x, s2, 0.5f * s2, r, y, hy)) {
+            ++ok;
+            if (rrt_f2u(r) != rrt_f2u(want)) { ++bad2; counters[4] = bits; counters[5] = rrt_f2u(s2); }
+        } else ++rej;
+    }
+    if (bad1) atomicAdd(counters, (unsigned long long)bad1);
+    if (bad2) atomicAdd(counters + 1, (unsigned long long)bad2);
+    atomicAdd(counters + 2, ok);
+    atomicAdd(counters + 3, rej);
 }
 
 /* rrt_div_tame against IEEE `/` on `n` pseudo-random tame operand pairs: |b| in 2^[-40, 40), |a| in 2^[-20, 20) times
@@ -2850,15 +2896,22 @@ int rrt_selfcheck_sqrt_seeded(uint32_t lo_bits, uint32_t hi_bits, unsigned long 
     RRT_HIP(hipGetLastError());
     return RRT_OK;
 }
+int rrt_selfcheck_sqrt_boundaries(int e_lo, int e_hi, int span, unsigned n_seeds, float tol1, float tol2, unsigned long long* d_counters, void* st) {
+    if (!d_counters || e_lo >= e_hi || e_lo < -60 || e_hi > 100 || span < 0 || span > 4096 || n_seeds == 0 || !(tol1 >= 0.0f) || !(tol2 >= 0.0f))
+        return RRT_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(k_selfcheck_sqrt_boundaries, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(st), e_lo, e_hi, span, n_seeds, tol1, tol2, d_counters);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
 int rrt_selfcheck_div_tame(unsigned long long n, uint32_t seed, unsigned long long* d_counters, void* st) {
     if (!d_counters) return RRT_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(k_selfcheck_div_tame, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(st), n, seed, d_counters);
     RRT_HIP(hipGetLastError());
     return RRT_OK;
 }
-int rrt_selfcheck_div_march(unsigned long long n, uint32_t seed, unsigned long long* d_counters, void* st) {
-    if (!d_counters) return RRT_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(k_selfcheck_div_march, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(st), n, seed, d_counters);
+int rrt_selfcheck_div_march(unsigned long long n, uint32_t seed, float tol1, float tol2, unsigned long long* d_counters, void* st) {
+    if (!d_counters || !(tol1 >= 0.0f) || !(tol2 >= 0.0f)) return RRT_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(k_selfcheck_div_march, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(st), n, seed, tol1, tol2, d_counters);
     RRT_HIP(hipGetLastError());
     return RRT_OK;
 }

@@ -1215,8 +1215,10 @@ def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
     g, rrt, tex = ctx
     rng = np.random.default_rng(int(os.environ.get("RRT_SWEEP_SEED", "20261004")))     # soaks vary the seed
     ample, starved = rrt.Workspace(512 << 20), rrt.Workspace(13 << 20)     # 13 MiB: the smallest useful pool
+    mid = rrt.Workspace(64 << 20)                                          # two chains need >= 4096 blocks: rounds AND chains
     nt = rrt.NoiseTable(30.0)
     order = rrt.TileOrder()
+    order3 = rrt.TileOrder()
     try:
         overflowed = 0
         for case in range(int(os.environ.get("RRT_SWEEP_CASES", "60"))):      # soak: RRT_SWEEP_CASES=600 (run on the round's final build)
@@ -1273,6 +1275,17 @@ def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
                 torch.cuda.synchronize()
                 assert torch.equal(out, want), (tag, pool.nbytes, pool.stats())
             overflowed += starved.stats()["overflow_waves"]
+            # round 4: rounds over a small pool (nothing may take the in-line route), two chains forced on these small
+            # launches, the three-pass path under cost-ordered dispatch (probe-seeded on a scene's first launch)
+            for pool, rounds, chains, oid in ((starved, 64, 1, 0), (mid, 48, 2, 0), (ample, 0, 2, order3.id), (mid, 48, 2, order3.id)):
+                out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+                rrt.launch_raymarch(out, w, h, t, cam, tex, fx,
+                                    rrt.RenderParams(spin=spin, workspace=pool.id, path_policy=2, pool_rounds=rounds, pass_chains=chains,
+                                                     tile_order=oid, noise_table=nt.id if case % 2 else 0))
+                torch.cuda.synchronize()
+                assert torch.equal(out, want), (tag, "rounds / chains", pool.nbytes, rounds, chains, oid, pool.stats())
+                if rounds:
+                    assert pool.stats()["overflow_waves"] == 0, (tag, pool.nbytes, pool.stats())
             n, R = int(rng.integers(2, 6)), int(rng.integers(1, 9))
             frame = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
             for s in range(n):
@@ -1284,8 +1297,22 @@ def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
                     rrt.assemble_tiles(frame, buf, w, h, R, s, n)
             torch.cuda.synchronize()
             assert torch.equal(frame, want), (tag, n, R)
+            # the same shards under an arbitrary tile -> shard map, gathered layout, one assemble
+            n_tiles = (h + R - 1) // R
+            tm = rrt.TileMap(h, R, n, rng.integers(0, n, n_tiles).astype(np.int32))
+            stride = max(tm.max_shard_rows(), 1) * w * 4
+            allbuf = torch.zeros(n * stride, dtype=torch.uint8, device="cuda")
+            for s in range(n):
+                if tm.shard_rows(s):
+                    rrt.launch_raymarch_tilemap(allbuf[s * stride:], w, h, tm, s, t, cam, tex, fx,
+                                                rrt.RenderParams(spin=spin, workspace=ample.id, path_policy=2 * (s % 2), noise_table=nt.id if case % 2 else 0))
+            frame.zero_()
+            rrt.assemble_all_tilemap(frame, allbuf, stride, w, h, tm)
+            torch.cuda.synchronize()
+            assert torch.equal(frame, want), (tag, "tile map", n, R)
+            tm.destroy()
         assert overflowed > 0          # the starved pool did exercise the overflow route somewhere in the sweep
         info = order.info()
         assert info["ordered_launches"] >= info["launches"] // 2       # every scene's second launch (at least) was cost-ordered
     finally:
-        ample.destroy(); starved.destroy(); nt.destroy(); order.destroy()
+        ample.destroy(); starved.destroy(); mid.destroy(); nt.destroy(); order.destroy(); order3.destroy()

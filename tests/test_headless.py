@@ -124,6 +124,23 @@ def test_cpp_driver_rccl_gather_path_writes_the_same_frames(tmp_path):
     assert subprocess.run([exe] + base + ["--frames-in-flight", "5"], capture_output=True).returncode == 2
 
 
+@pytest.mark.gpu
+def test_cpp_driver_watchdog_ends_a_stuck_run_with_a_diagnosis():
+    """a run that makes no progress must END -- status 3, where it sat, the last trace points, every
+    communicator's asynchronous error -- instead of hanging until a harness kills it.  Provoked here by a bring-up limit
+    shorter than any communicator bring-up (RCCL loads its code object for over a second even with a warm page cache)."""
+    from relativisticraytracer_amd import build
+    exe = build.build_headless()
+    r = subprocess.run([exe, "--width", "64", "--height", "36", "--frames", "2", "--force-collective", "--init-timeout", "0.3"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    assert "no progress for" in r.stderr and "Last trace points" in r.stderr and "start" in r.stderr
+    assert "{" not in r.stdout                                   # no summary line: the run did not complete
+    # the same run with the default limits completes
+    r = subprocess.run([exe, "--width", "64", "--height", "36", "--frames", "2", "--force-collective"], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["frames"] == 2
+
+
 def _gpu_count():
     import torch
     return torch.cuda.device_count()
