@@ -755,6 +755,24 @@ def test_streams_graph_capture_and_borrowed_sky(ctx, sky):
         assert torch.equal(c2, ref) and torch.equal(live, ref)
     assert order.info()["launches"] == before["launches"] + 3
     order.destroy()
+    # the three-pass path under capture: one chain (the workspace's side stream stays out of a capture), rounds as enqueued
+    wsg = rrt.Workspace(64 << 20)
+    d3 = torch.zeros_like(ref)
+    p3 = rrt.RenderParams(spin=0.9, workspace=wsg.id, path_policy=2, pool_rounds=3)
+    rrt.launch_raymarch(d3, w, h, 1.0, cam, tex, fx, p3)
+    torch.cuda.synchronize()
+    assert torch.equal(d3, ref)
+    graph3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph3):
+        rrt.launch_raymarch(d3, w, h, 1.0, cam, tex, fx, p3)
+    for _ in range(2):
+        d3.zero_()
+        graph3.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(d3, ref)
+    assert wsg.stats()["rounds_enqueued"] == 3 and wsg.stats()["overflow_waves"] == 0
+    del graph3
+    wsg.destroy()
     # borrowed device sky
     dsky = torch.from_numpy(sky).cuda()
     hnd = C.c_ulonglong(0)

@@ -24,6 +24,32 @@ for name in (sys.argv[4:] or list(VIEWS)):
     rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id))
     torch.cuda.synchronize()
     got = out.cpu().numpy().reshape(h, w, 4)[np.ix_(rows, xs)]
+    if os.environ.get("RRT_DENSE_SHARDS"):
+        # the same frame the way N ranks render it (round 4): tiles dealt by the probe's costs (rrt_tile_map), every shard
+        # through the three-pass path -- two chains, a 2 GiB pool used in rounds, cost-ordered dispatch seeded by the probe --
+        # gathered layout, ONE rrt_assemble_all_tilemap: must be the single launch's bytes, every pixel
+        N, R = int(os.environ["RRT_DENSE_SHARDS"]), 16
+        cost = rrt.probe_tile_costs(w, h, R, t, cam, fx, rrt.RenderParams(spin=0.9))
+        tm = rrt.TileMap(h, R, N, rrt.balance_tiles(cost, N))
+        ws = rrt.Workspace(2048 << 20)
+        stride_b = tm.max_shard_rows() * w * 4
+        allbuf = torch.zeros(N * stride_b, dtype=torch.uint8, device="cuda")
+        fallbacks = rounds = 0
+        for sh in range(N):
+            order = rrt.TileOrder()
+            rrt.launch_raymarch_tilemap(allbuf[sh * stride_b:], w, h, tm, sh, t, cam, tex, fx,
+                                        rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=ws.id, path_policy=2, pool_rounds=24, tile_order=order.id))
+            torch.cuda.synchronize()
+            st = ws.stats(); fallbacks += st["overflow_waves"]; rounds = max(rounds, st["rounds_with_work"])
+            order.destroy()
+        frame = torch.zeros_like(out)
+        rrt.assemble_all_tilemap(frame, allbuf, stride_b, w, h, tm)
+        torch.cuda.synchronize()
+        diff = int((frame != out).sum())
+        bad_total += diff
+        print(f"{name:8s} as {N} shards (probe-dealt tile map, three-pass, two chains, 2 GiB pool: {rounds} rounds with work, {fallbacks} in-line "
+              f"fall-backs, probe-seeded dispatch order), one assemble: bytes different from the single launch: {diff} of {frame.numel()}", flush=True)
+        ws.destroy(); tm.destroy(); del allbuf, frame
     a = cam.as_array()
     t0 = time.perf_counter()
     o = po.render(po.camera(a[0], a[1], a[2], a[3]), po.default_effects(),
