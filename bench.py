@@ -285,6 +285,18 @@ def main():
         fs.step(); it["i"] += 1
     fs.flush()
     barrier()
+    # The shader clock the chip HOLDS during the timed frames: rrt_clock_probe -- ONE wavefront that sleeps and
+    # reads the shader-clock counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) at both ends -- runs on a
+    # second stream BESIDE the timed frames, for about three quarters of their expected duration (from the warm-up frames'
+    # kernel times, so that it has ended before they have; without warm-up frames it runs beside two extra frames afterwards).
+    # One sleeping wave of 8 192 slots does not move the measurement.
+    clock_ghz, clock_when = None, None
+    cbuf = torch.zeros(2, dtype=torch.int64, device=dev) if world == 1 else None
+    side = torch.cuda.Stream() if world == 1 else None
+    if world == 1 and args.warmup > 0:
+        warm_ms = min(a.elapsed_time(b) for a, b in ev[:args.warmup])
+        rrt.clock_probe(cbuf, int(min(2_000_000, max(1_000, 0.75 * args.steps * warm_ms * 1000.0))), stream=side)
+        clock_when = "beside the timed frames"
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fs.step(); it["i"] += 1
@@ -297,19 +309,14 @@ def main():
         dt = float(tt.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev[args.warmup:args.warmup + args.steps]]
 
-    # The shader clock the chip HOLDS under this very load (boxes of this pool hold 2.21-2.40 GHz, which moved
-    # the roofline fraction by 4 % with nothing in the record to say why).  Untimed: two more frames of the same workload
-    # with rrt_clock_probe beside them on a second stream -- one wavefront that sleeps and reads the shader-clock counter
-    # (s_memtime) and the constant 100 MHz counter (s_memrealtime) at both ends.
-    clock_ghz = None
     if world == 1:
-        side = torch.cuda.Stream()
-        cbuf = torch.zeros(2, dtype=torch.int64, device=dev)
-        est_ms = float(np.mean(kernel_ms)) if kernel_ms else 40.0
-        side.wait_stream(torch.cuda.current_stream())
-        rrt.clock_probe(cbuf, int(min(2_000_000, max(2_000, 1.7 * est_ms * 1000.0))), stream=side)
-        for _ in range(2):
-            fs.step(); it["i"] += 1
+        if clock_when is None:                 # --warmup 0: beside two untimed frames of the same workload, afterwards
+            est_ms = float(np.mean(kernel_ms)) if kernel_ms else 40.0
+            side.wait_stream(torch.cuda.current_stream())
+            rrt.clock_probe(cbuf, int(min(2_000_000, max(2_000, 1.7 * est_ms * 1000.0))), stream=side)
+            for _ in range(2):
+                fs.step(); it["i"] += 1
+            clock_when = "beside two untimed frames after the timed ones"
         torch.cuda.synchronize()
         cc = cbuf.cpu().numpy()
         if cc[1] > 0:
@@ -505,8 +512,9 @@ def main():
                          "clock_ghz": round(clock_ghz, 4) if clock_ghz else None,
                          "frac_at_held_clock": round(tops / (256 * 4 * 32 * clock_ghz * 1e9 / 1e12), 4) if clock_ghz else None,
                          "clock_note": "shader clock held under this workload: s_memtime / s_memrealtime of a one-wave probe (rrt_clock_probe) "
-                                       "running beside two untimed frames; `peak` prices 2.4 GHz, frac_at_held_clock the clock the chip "
-                                       "actually ran at (boxes of this pool hold 2.2-2.4 GHz)",
+                                       "running " + str(clock_when) + "; `peak` prices 2.4 GHz, frac_at_held_clock the clock the chip actually ran at "
+                                       "(boxes of this pool hold 2.2-2.4 GHz); > 1 is possible: the peak counts one SOURCE operation per lane and clock "
+                                       "and the kernel needs 0.955 instructions per source operation",
                          "traffic_note": traffic_note,
                          "frac_of_fma_peak_157.3": round(tops / 157.3, 4),
                          "kernel": "raymarch_pixels", "kernel_ms": round(k_ms, 3),

@@ -169,10 +169,13 @@ int rrt_sky_create_from_device(const void* d_rgba8, int width, int height, rrt_s
 int rrt_sky_destroy(rrt_sky_t sky);
 
 /* ---- workspace of the three-pass path (rrt_params.workspace): a caller-owned HBM pool, so that a
- *      launch still allocates nothing.  One workspace serves one stream at a time.  ~1.5 KB per
- *      wave-step that touches the media (handed out in blocks of 8); the 4K bench frame uses ~4 GB.  If the pool runs out, the
- *      rays it ran out under are finished by the in-line code from where they stopped (same result,
- *      slower). ---- */
+ *      launch still allocates nothing.  One workspace serves one stream at a time (it owns a second stream of its
+ *      own for the second chain, rrt_params.pass_chains; forked from and joined to the caller's by events).  ~1.5 KB per
+ *      wave-step that touches the media (handed out in blocks of 8 rows, runs of up to 8 blocks); the 4K bench frame
+ *      pools 2.6 GB, an eighth of it 0.3 GB, an eighth of a 4K view from inside the disk 1.9 GB.  The pool is reused in
+ *      ROUNDS (rrt_params.pool_rounds): the wavefronts it runs out under are suspended and resumed once the pooled
+ *      samples have been evaluated and composited, so any pool serves any view; only rays still suspended after the last
+ *      enqueued round are finished by the in-line code (same result either way; one round is the fast case). ---- */
 int rrt_workspace_create(size_t bytes, int* out_id);
 int rrt_workspace_destroy(int id);
 /* after a launch has completed: rows used and wavefronts that fell back (synchronous read) */

@@ -275,8 +275,14 @@ RRT_DEV void sqrt_rsq(float x, float& root, float& inv_root) {
  * rrt_selfcheck_div on 2^44 march-shaped operand sets (3.5e13 divides, tools/div_rounds_probe.py,
  * profiles/r03_div_rounds_probe.txt): ONE correction 2 mismatches, TWO corrections the same 2 mismatches, both on
  * denominators whose significand is within 5 ulp of 2 (0x4bfffffb: Markstein's known exception, where the refined
- * reciprocal itself is off and no number of residual corrections repairs it).  That floor, 6e-14 per divide = one
+ * reciprocal itself is off and no number of residual corrections repairs it).  That floor, 5.7e-14 per divide = one
  * acceleration in ~250 4K frames, was already in round 2's build; VERDICT r02 asked for >= 2^34 clean cases.
+ * THE DOCUMENTED EXCEPTION of "correctly rounded division" (round 4): a denominator whose significand lies an odd number
+ * d <~ 11 of ulps below 2 has a reciprocal within d^2/4 * 2^-46 of a rounding tie, closer than the 2^-42 the once-refined
+ * reciprocal carries; with a seed a few ulps off, y comes out one ulp low and the quotient with it.  Pinned as an expected
+ * mismatch by tests/test_gpu_units.py::test_divide_known_exception_is_what_the_documents_say (0x33666662 / 0x4bfffffb, seed
+ * 0x33000006); closing it would take two more instructions on each of the 8 divides of a step (5.6 %).  With seeds as the
+ * march's own roots produce them: 0 mismatches in 2.2e13 divides (rrt_selfcheck_div_march, profiles/r04_div_march_seeds_probe.txt).
  */
 #ifndef RRT_DIV_ROUNDS
 #define RRT_DIV_ROUNDS 1

@@ -270,6 +270,7 @@ int main(int argc, char** argv) {
         Device& D = dev[d];
         D.id = d;
         HIPCHK(hipSetDevice(d));
+        const int rows = collective ? D.shard_rows : h;            // image rows of one launch on this device
         if ((rc = rrt_sky_create(sky.data(), 2048, 1024, &D.sky)) != RRT_OK) return fail("sky", rc);
         HIPCHK(hipMalloc(&D.probe, 256 * (size_t)(gpus + 1)));
         HIPCHK(hipEventCreateWithFlags(&D.comm_free, hipEventDisableTiming));
@@ -278,9 +279,13 @@ int main(int argc, char** argv) {
             HIPCHK(hipMalloc(&D.tiles[s], shard_stride));
             if (workspace_gib > 0 && (rc = rrt_workspace_create(((size_t)workspace_gib << 30) / kSlots, &D.pool[s])) != RRT_OK)
                 return fail("workspace", rc);
-            // every frame's wave tiles dispatched longest-first by what the slot's previous frame measured: worth it when the
-            // frames do not overlap (their drains are exposed), a wash when they do
-            if ((tile_order == 1 || (tile_order < 0 && kSlots == 1)) && (rc = rrt_tile_order_create(&D.order[s])) != RRT_OK)
+            // every frame's wave tiles dispatched longest-first by what the slot's previous frame measured (the first frame: by
+            // the library's probe of the view): worth it when the frames do not overlap (their drains are exposed) AND the
+            // launch takes the single kernel; a wash when frames overlap, and measured harmful on the three-pass path's two
+            // chains (it piles every expensive tile into the first chain: an eighth of a 4K frame 5.15 -> 5.45 ms, of a
+            // disk-heavy one 7.7 -> 10.6; profiles/r04_shard_kernel_times_*.txt), which is what small launches with a pool take
+            const bool three_pass_likely = workspace_gib > 0 && (long long)w * rows <= 1500000ll;
+            if ((tile_order == 1 || (tile_order < 0 && kSlots == 1 && !three_pass_likely)) && (rc = rrt_tile_order_create(&D.order[s])) != RRT_OK)
                 return fail("tile order", rc);
         }
     }

@@ -9,8 +9,11 @@
  *
  * Kernels
  *   raymarch_pixels<SPIN,VOL,DEBUG,FAST>   single-kernel path: one ray per lane, media sampled in line
- *   march_defer / eval_sample_rows / composite_and_shade
- *                                          three-pass path through a caller-owned workspace
+ *   march_defer / eval_sample_rows / composite_and_shade (/ pool_next_round)
+ *                                          three-pass path through a caller-owned workspace: in rounds over the pool, as two
+ *                                          chains on two streams (round 4)
+ *   probe_costs / probe_to_tiles           coarse march-only probe of a view: first-frame dispatch order, row-tile costs
+ *   clock_probe_kernel                     the shader clock the chip holds
  *   assemble_tiles_kernel / assemble_all_kernel   scatter gathered row-tile shards into the frame
  *   k_* / k_selfcheck_*                    array wrappers of the device functions (tests only)
  * Host
@@ -107,7 +110,7 @@ rrt_sky_t sky_register(const SkyObject& s) {
  * pool in HBM; pass 2 evaluates the densities + emission of every row with the whole chip, wherever
  * the row came from; pass 3 composites each ray's samples in march order and shades the pixel.
  * The pool is handed out in blocks of kBlockRows rows, and blocks in runs of consecutive blocks whose
- * length doubles (1, 2, 4 ... kMaxRun) every time a wave comes back for more: one atomic per run (a
+ * length doubles (1, 2, 4 ... kMaxRun = 8) every time a wave comes back for more: one atomic per run (a
  * single counter saturates near 90 atomics/us) and only ~log2(n) dependent pointer hops when pass 3
  * walks a heavy wave's samples.  Block layout: kBlockRows x six SoA float[64] planes (p.xyz, vel.xyz in;
  * ex, ey, ez, transmittance out in planes 0-3), then a trailer {lane mask of each row; in the first
@@ -128,7 +131,15 @@ struct DeferCounters {
 /* state: 0 untouched, 1 marched to its end this round, 2 suspended (the pool ran out under it), 3 shaded.
  * flags bit 0: the rays' radiance so far is saved in `finals` (planes 7-10). */
 struct WaveHdr { unsigned first_block, n_runs, state, flags; };
-constexpr unsigned kMaxRun = 32;
+/* Longest run of blocks a wave takes at once.  Runs double (1, 2, 4 ...) up to this, and a wave's last run is on average half
+ * empty: with 32 (rounds 1-3) an eighth of the 4K frame from inside the disk allocated 1.46 M rows for 1.2 M samples' worth and
+ * needed a second -- sparse, latency-bound -- round in a 2 GiB pool; with 8 it allocates 1.28 M, fits, and takes 7.9 instead of
+ * 9.6 ms; the bench view is indifferent (profiles/r04_max_run_ab.txt).  Shorter runs mean more atomics (one per run: ~20 k per
+ * such frame, spread over milliseconds) and more link hops in pass 3 (a 2000-row wave: 32 instead of 12). */
+#ifndef RRT_MAX_RUN
+#define RRT_MAX_RUN 8
+#endif
+constexpr unsigned kMaxRun = RRT_MAX_RUN;
 constexpr unsigned kMaxRunsWalked = 4096;                          /* runs of one wave that pass 3 will walk */
 constexpr unsigned kBlockRows = 8;
 constexpr unsigned kRowData = 6 * 256;
@@ -983,6 +994,14 @@ __global__ __launch_bounds__(kWGThreads, RRT_DEFER_WAVES) RRT_DEFER_SGPR_ATTR vo
     if (a.tile_cost) add_tile_cost(a, t_start);
 }
 
+/* zero the workspace's counters and wave headers.  A kernel, not hipMemsetAsync: the memset NODE a captured launch turned
+ * into did not reliably clear them on a second replay of the graph (counters came back holding the previous replay's values
+ * plus stray words; round 4, tests/test_gpu_frames.py::test_streams_graph_capture_and_borrowed_sky) */
+__global__ __launch_bounds__(256) void zero_words(uint4* p, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 /* between two rounds (one thread): close the round's statistics and empty the pool */
 __global__ void pool_next_round(DeferCounters* c, unsigned capacity, int last) {
     const unsigned used = c->next_block < capacity ? c->next_block : capacity;
@@ -1767,7 +1786,7 @@ int fill_args(FrameArgs& a, LaunchOpts& o, void* out, int width, int height, flo
  * resume flags (30 bits), and pass 3 walks at most kMaxRunsWalked runs of a wave, whose lengths double up to
  * kMaxRun blocks of kBlockRows rows -- a wave can pool one row per step, so it must not need more runs than
  * that.  Launches with more steps take the single kernel (same bytes). */
-constexpr long long kThreePassMaxSteps = (long long)(kMaxRunsWalked - 8) * kMaxRun * kBlockRows;   /* ~1.05 M */
+constexpr long long kThreePassMaxSteps = (long long)(kMaxRunsWalked - 8) * kMaxRun * kBlockRows;   /* ~262 k */
 static_assert(kThreePassMaxSteps < (1ll << 30), "step count must fit beside the two flag bits");
 constexpr int kFinalPlanes = 11;      /* per ray: vel xyz, code, pos xyz, radiance rgbt */
 constexpr int kMaxPoolRounds = 64;
@@ -1857,7 +1876,9 @@ int launch_deferred(FrameArgs a, bool fast, bool lut, const WorkspaceObject& ws,
         if (st != nullptr && hipStreamIsCapturing(st, &capst) != hipSuccess) { (void)hipGetLastError(); capst = hipStreamCaptureStatusNone; }
         if (capst == hipStreamCaptureStatusNone) chains = 2;
     }
-    RRT_HIP(hipMemsetAsync(ws.d_base, 0, off_fin, st));            /* counters + wave headers */
+    hipLaunchKernelGGL(zero_words, dim3((unsigned)((off_fin / 16 + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<uint4*>(ws.d_base), off_fin / 16);        /* counters + wave headers (off_fin is a multiple of 256) */
+    RRT_HIP(hipGetLastError());
     /* the pool's split: by what each chain pooled last time (the heavy half holds most of the media), 65 : 35 without history */
     size_t cap_of[kMaxChains] = {cap, 0};
     int row_end[kMaxChains] = {(int)grid.y, (int)grid.y};

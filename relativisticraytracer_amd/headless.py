@@ -103,7 +103,11 @@ def main(argv=None):
     t_end, _ = camera_paths.recording_clock(max(args.frames, 1), args.fps)
     nwin = rrt.NoiseWindows(float(t_end) + 1.0, int(args.noise_table_gib * (1 << 30)), sync=torch.cuda.synchronize,
                             enabled=not args.no_noise_table and not args.no_volumetrics)
-    use_order = args.tile_order == "on" or (args.tile_order == "auto" and n_slots == 1)
+    # cost-ordered dispatch pays on single-kernel launches whose frames do not overlap; on the three-pass path (small launches
+    # with a pool) it piles the expensive tiles into the first of the two chains and was measured slower: auto leaves it off there
+    my_rays = w * sharding.shard_rows(h, args.tile_rows, rank, world)
+    three_pass_likely = bool(pools) and my_rays <= 1_500_000
+    use_order = args.tile_order == "on" or (args.tile_order == "auto" and n_slots == 1 and not three_pass_likely)
     orders = [rrt.TileOrder() for _ in range(n_slots)] if use_order else []
     prms = [rrt.RenderParams(spin=args.spin, volumetrics=0 if args.no_volumetrics else 1,
                              noise_table=0, tile_order=orders[j].id if orders else 0,
