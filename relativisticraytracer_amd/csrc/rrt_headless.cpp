@@ -134,9 +134,11 @@ void watchdog(double init_limit_s, double frame_limit_s) {
             fprintf(stderr, "rrt_headless: no progress for %.0f s in \"%s\" -- giving up.  Last trace points:\n", idle * 1e-9,
                     g_tr.phase.load());
             dump_trace();
-            for (size_t d = 0; d < g_tr.comms.size(); ++d) {
+            std::vector<ncclComm_t> comms;
+            { std::lock_guard<std::mutex> lk(g_tr.mu); comms = g_tr.comms; }
+            for (size_t d = 0; d < comms.size(); ++d) {
                 ncclResult_t async = ncclSuccess;
-                const ncclResult_t q = ncclCommGetAsyncError(g_tr.comms[d], &async);
+                const ncclResult_t q = ncclCommGetAsyncError(comms[d], &async);
                 fprintf(stderr, "  communicator %zu: ncclCommGetAsyncError -> %s, async error: %s\n", d, ncclGetErrorString(q),
                         ncclGetErrorString(async));
             }
@@ -299,7 +301,7 @@ int main(int argc, char** argv) {
         NCCLCHK(ncclCommInitAll(comms.data(), gpus, ids.data()));
         trace("ncclCommInitAll done");
         for (int d = 0; d < gpus; ++d) dev[d].comm = comms[d];
-        g_tr.comms = comms;
+        { std::lock_guard<std::mutex> lk(g_tr.mu); g_tr.comms = comms; }
         // One untimed exchange of a few bytes brings up the peer-to-peer channels and loads RCCL's code object now, under
         // the bring-up limit, instead of under frame 1's.
         trace("first exchange (channel set-up) ...");

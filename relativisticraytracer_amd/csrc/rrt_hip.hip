@@ -1956,13 +1956,14 @@ int tile_order_reserve(TileOrderObject& o, size_t n) {
 }
 
 /* enqueue the coarse probe of the launch `a` describes (its row map included) into `cells` */
-int enqueue_probe(const FrameArgs& a, ProbeArgs& q, unsigned* cells, int stride_x, int stride_y, hipStream_t st) {
+int enqueue_probe(const FrameArgs& a, ProbeArgs& q, unsigned* cells, int stride_x, int stride_y, bool media, hipStream_t st) {
     q.cell_cost = cells;
     q.stride_x = stride_x; q.stride_y = stride_y;
     q.cells_x = (a.width + stride_x - 1) / stride_x;
     q.cells_y = (a.rows.n_local_rows + stride_y - 1) / stride_y;
     q.w_step = RRT_PROBE_W_STEP; q.w_acc = RRT_PROBE_W_ACC; q.w_dust = RRT_PROBE_W_DUST;
     q.ring_steps = (float)a.max_steps;
+    if (!media) { q.w_acc = 0.0f; q.w_dust = 0.0f; }          /* volumetrics off: a sample costs nothing, the steps stay */
     if (const char* e = getenv("RRT_PROBE_WEIGHTS")) {          /* dev: tools/probe_fit.py reads the three counts one at a time */
         float w0, w1, w2;
         if (sscanf(e, "%f,%f,%f", &w0, &w1, &w2) == 3) { q.w_step = w0; q.w_acc = w1; q.w_dust = w2; }
@@ -2018,7 +2019,7 @@ int launch(const FrameArgs& a, const LaunchOpts& o, bool debug, hipStream_t st) 
             if (!same && !order->no_seed) {
                 /* first launch of this geometry: probe -> per-tile estimate -> order */
                 ProbeArgs q;
-                rc = enqueue_probe(a, q, order->d_sorted, kProbeStride, kProbeStride, st);   /* d_sorted: scratch until the sort */
+                rc = enqueue_probe(a, q, order->d_sorted, kProbeStride, kProbeStride, o.media != 0, st);   /* d_sorted: scratch until the sort */
                 if (rc != RRT_OK) return rc;
                 hipLaunchKernelGGL(probe_to_tiles, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, order->d_cost, grid.x, grid.y, q);
                 RRT_HIP(hipGetLastError());
@@ -2751,7 +2752,7 @@ int rrt_probe_tile_costs(int width, int height, int tile_rows, float time, const
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_cells), (size_t)cells_x * cells_y * sizeof(unsigned));
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(probe)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = enqueue_probe(a, q, d_cells, kProbeStride, sy, st);
+    int rc = enqueue_probe(a, q, d_cells, kProbeStride, sy, p.volumetrics != 0, st);
     std::vector<unsigned> cells((size_t)cells_x * cells_y);
     if (rc == RRT_OK) {
         e = hipMemcpyAsync(cells.data(), d_cells, cells.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st);
