@@ -18,7 +18,7 @@ view = sys.argv[1] if len(sys.argv) > 1 else "default"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 pool_mib = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
 spin = float(sys.argv[4]) if len(sys.argv) > 4 else 0.9
-W, H, R = 3840, 2160, 16
+W, H, R = 3840, 2160, int(os.environ.get("RRT_TILE_ROWS", "16"))
 pos, yaw, pitch, t = VIEWS[view]
 cam = rrt.CameraState.from_angles(pos, yaw, pitch)
 tex = rrt.SkyTexture(synthetic_sky()); fx = rrt.CameraEffects(); nt = rrt.NoiseTable(32.0)
