@@ -22,7 +22,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
  *     launches are asynchronous exactly like the reference's (raymarcher.cu:179);
  *   - the library keeps no per-call state and allocates nothing in a launch,
- *     so launches may be captured into a hipGraph.
+ *     so launches may be captured into a hipGraph (what a launch needs beyond its arguments -- a pool, noise tables, a
+ *     tile-order object -- are caller-owned objects created beforehand; the one exception is documented at
+ *     rrt_tile_order: its FIRST launch of a larger geometry sizes its buffers, and captured launches ignore it).
  */
 #ifndef RRT_H
 #define RRT_H
@@ -280,7 +282,7 @@ int rrt_launch_raymarch_rows(void* d_out_rows, int width, int height, int y0, in
 /* Interleaved row-tile variant: tile t = image rows [t*tile_rows, (t+1)*tile_rows)
  * belongs to shard (t mod n_shards).  Renders all tiles of `shard` into
  * d_out_tiles, tile-major in increasing t, each tile stored bottom-up like
- * rrt_launch_raymarch_rows.  rrt_tile_shard_bytes() gives the buffer size. */
+ * rrt_launch_raymarch_rows.  rrt_tile_shard_rows() gives the buffer's rows (x width x 4 bytes). */
 int rrt_launch_raymarch_tiles(void* d_out_tiles, int width, int height, int tile_rows,
                               int shard, int n_shards, float time,
                               const rrt_camera* cam, rrt_sky_t sky, const rrt_effects* fx,
