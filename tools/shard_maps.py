@@ -68,13 +68,14 @@ def run(assignment, chains, collect=None, ordered=False):
 
 modulo = (np.arange(n_tiles) % N).astype(np.int32)
 measured = np.zeros(n_tiles)
-one_t, one_s = run(modulo, 1, collect=measured)
+can_collect = R % 8 == 0 and H % R == 0                       # the per-tile sums below assume whole wave tiles per row tile
+one_t, one_s = run(modulo, 1, collect=measured if can_collect else None)
 probe = rrt.probe_tile_costs(W, H, R, t, cam, fx, rrt.RenderParams(spin=spin))
 cases = [("t mod N, one chain (round 3's path)", modulo, 1, False, (one_t, one_s)),
          ("t mod N, two chains", modulo, 0, False, None),
          ("t mod N, two chains, cost-ordered dispatch", modulo, 0, True, None),
          ("dealt by the probe's estimate, two chains", rrt.balance_tiles(probe, N), 0, False, None),
-         ("dealt by measured costs, two chains", rrt.balance_tiles(measured.astype(np.float32), N), 0, False, None)]
+         ] + ([("dealt by measured costs, two chains", rrt.balance_tiles(measured.astype(np.float32), N), 0, False, None)] if can_collect else [])
 for name, m, chains, ordered, done in cases:
     ts, st = done if done else run(m, chains, ordered=ordered)
     cnt = np.bincount(m, minlength=N)
