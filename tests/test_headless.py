@@ -249,6 +249,11 @@ def test_bench_line_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
+    # round 4: the clock the chip held over the timed frames, and the fraction priced at it
+    assert 1.0 < rf["clock_ghz"] < 2.6 and "beside the timed frames" in rf["clock_note"]
+    assert abs(rf["frac_at_held_clock"] - rf["achieved"] / (256 * 4 * 32 * rf["clock_ghz"] / 1e3)) < 2e-3
+    hv = d["heavy_view"]
+    assert hv["noise_table_first_frame_probe_ordered"]["ms_per_step"] > 0 and hv["noise_table_cost_ordered"]["ms_per_step"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]
     if cb["kind"] == "reference":       # oracle/_ref travelled with the tree: the reference's own kernel body was timed
