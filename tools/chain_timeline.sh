@@ -14,7 +14,7 @@ starts=sorted(int(r["Start_Timestamp"]) for r in rows if "march_defer" in r["Ker
 t0=starts[-2] if len(starts)>1 else starts[-1]
 for r in rows:
     if int(r["Start_Timestamp"]) < t0: continue
-    n=r["Kernel_Name"]; n=n[n.find("::")+2:n.find("(")]
+    n=r["Kernel_Name"]; n=n.split("::")[-2 if n.count("::")>1 else -1] if False else n[n.find("namespace)::")+12:][:44]
     d=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6
     if d < 0.02: continue
     print(f'{(int(r["Start_Timestamp"])-t0)/1e6:8.3f} -> {(int(r["End_Timestamp"])-t0)/1e6:8.3f} ms ({d:6.3f})  q{r.get("Queue_Id","?")}  {n[:60]}')

@@ -10,7 +10,8 @@ K = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 view = sys.argv[4] if len(sys.argv) > 4 else "default"
 order_on = len(sys.argv) > 5 and sys.argv[5] == "order"
 chains = int(os.environ.get("RRT_CHAINS", "0"))
-V = {"default": ((0.0, 10.0, -60.0), 0.0, -10.0, 1.0), "skimmer": ((4.2, 0.6, 4.2), -90.0, -5.7, 14.0)}[view]
+V = {"default": ((0.0, 10.0, -60.0), 0.0, -10.0, 1.0), "skimmer": ((4.2, 0.6, 4.2), -90.0, -5.7, 14.0),
+     "key1": ((15.0, 3.0, -30.0), -26.6, -5.1, 6.0), "grazing": ((35.0, 0.8, 10.0), -106.0, -1.2, 12.0)}[view]
 W, H, R = 3840, 2160, 16
 cam = rrt.CameraState.from_angles(*V[:3]); t = V[3]
 tex = rrt.SkyTexture(synthetic_sky()); fx = rrt.CameraEffects(); nt = rrt.NoiseTable(32.0)
