@@ -700,6 +700,52 @@ def test_first_frame_order_comes_from_the_probe(ctx):
         order.destroy(); plain.destroy()
 
 
+def test_two_host_threads_with_their_own_objects_render_concurrently(ctx):
+    """launches through DIFFERENT tile-order objects (and workspaces) from different host threads no longer
+    serialise on a registry lock -- and must not corrupt each other: two threads, each with its own stream, order object
+    and pool, render different views through both paths at the same time (ctypes releases the GIL inside the library)."""
+    import threading
+    import torch
+    g, rrt, tex = ctx
+    fx = rrt.CameraEffects()
+    w, h = 320, 180
+    views = [(rrt.CameraState.default(), 1.0), (rrt.CameraState.from_angles((4.2, 0.6, 4.2), -90.0, -5.7), 14.0)]
+    refs = []
+    for cam, t in views:
+        r = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+        rrt.launch_raymarch(r, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9))
+        refs.append(r)
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(idx):
+        try:
+            cam, t = views[idx]
+            st = torch.cuda.Stream()
+            order, ws = rrt.TileOrder(), rrt.Workspace(48 << 20)
+            out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+            for k in range(12):
+                prm = rrt.RenderParams(spin=0.9, tile_order=order.id, workspace=ws.id if k % 2 else 0, path_policy=2 if k % 2 else 1,
+                                       pass_chains=2, pool_rounds=8)
+                with torch.cuda.stream(st):
+                    out.zero_()
+                    rrt.launch_raymarch(out, w, h, t, cam, tex, fx, prm, stream=st)
+                st.synchronize()
+                if not torch.equal(out, refs[idx]):
+                    errors.append((idx, k))
+            order.destroy(); ws.destroy()
+        except Exception as e:          # noqa: BLE001 -- reported through the list
+            errors.append((idx, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(120)
+        assert not th.is_alive()
+    assert not errors, errors
+
+
 def test_clock_probe_reports_a_plausible_shader_clock(ctx):
     g, rrt, tex = ctx
     ghz = rrt.clock_probe_ghz(5000)
