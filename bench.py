@@ -43,7 +43,7 @@ def source_hash():
     it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("rrt_hip.hip", "rrt_device.h", "rrt_math.h"):
+    for f in ("rrt_hip.hip", "rrt_device.h", "rrt_math.h", "rrt_tile_sort.h"):
         h.update(open(os.path.join(ROOT, "relativisticraytracer_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -163,7 +163,7 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=16)
     ap.add_argument("--cpu-stride", type=int, default=-1,
                     help="CPU baseline sample stride: -1 (default) = sized so that the leg runs ~12 s on this host, 0 = skip")
-    ap.add_argument("--no-fast", action="store_true", help="skip the informational RRT_ARITH_FAST leg")
+    ap.add_argument("--no-fast", action="store_true", help="skip the within-tolerance arithmetic modes (RRT_ARITH_FMAD / _FAST) and their account")
     ap.add_argument("--no-noise-table", action="store_true", help="hash every noise3D corner arithmetically (no lattice tables)")
     ap.add_argument("--no-heavy", action="store_true", help="skip the informational heavy-view leg")
     ap.add_argument("--frames-in-flight", type=int, default=3,
@@ -370,29 +370,97 @@ def main():
                                      "before the next starts (latency-bound strong scaling); step = max over ranks of render "
                                      "+ gather + assemble"}
 
-    # Informational second leg (single GPU only): the same frame in RRT_ARITH_FAST (FMA + rsq in the
-    # integrator).  It is NOT the parity path and never `value`; its deviation from the strict frame
-    # is measured right here on the full-size frame.
-    fast = None
+    # N > 1: what ONE GPU of this node needs for the same frame in the same process, the denominator a scaling figure should
+    # be quoted against: rank 0 renders the whole frame alone with the single kernel, in the static order
+    # and cost-ordered (rrt_tile_order), the other ranks wait at the barrier; best of the two is the reference.
+    single_ref = None
+    if world > 1:
+        if rank == 0:
+            full = torch.zeros(h * w * 4, dtype=torch.uint8, device=dev)
+            order = rrt.TileOrder()
+            single_ref = {}
+            for tag, oid in (("static_order", 0), ("cost_ordered", order.id)):
+                prm_s = rrt.RenderParams(spin=args.spin, volumetrics=1, noise_table=ntab.id if ntab else 0, tile_order=oid)
+                for _ in range(2):
+                    rrt.launch_raymarch(full, w, h, 1.0, cam, tex, fx, prm_s)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    rrt.launch_raymarch(full, w, h, 1.0, cam, tex, fx, prm_s)
+                torch.cuda.synchronize()
+                single_ref[tag + "_ms"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+            order.destroy()
+            single_ref["same_bytes_as_the_gathered_frame"] = bool(torch.equal(full, fs.frame.view(-1)))
+            del full
+        barrier()
+
+    # Second leg (single GPU only): the same frame in the WITHIN-TOLERANCE arithmetic modes -- RRT_ARITH_FMAD (multiply-adds
+    # fused, roots and divisions still correctly rounded: the arithmetic class of the reference's own nvcc build) and
+    # RRT_ARITH_FAST (also 1-ulp rsq, no correctly rounded divide).  Never `value`.  Their account is made right here on the
+    # full-size frame (relativisticraytracer_amd/conditioning.py, the same function tests/test_gpu_tolerance.py asserts on):
+    # every pixel of a mode's frame that is outside 1e-4 of the strict frame, takes another number of steps or has a byte off
+    # by more than one LSB must be ILL-CONDITIONED -- a pixel the strict arithmetic itself moves out of the tolerance when its
+    # primary direction is nudged by a few ulps.  `within_tolerance_mode` = the fastest mode whose account is clean.
+    wtol = None
     if world == 1 and not args.no_fast:
-        prm_f = rrt.RenderParams(spin=args.spin, volumetrics=1, arith_mode=1, noise_table=ntab.id if ntab else 0)
+        from relativisticraytracer_amd import conditioning
         strict_frame = fs.frame.clone()
         buf = torch.zeros_like(strict_frame)
-        for _ in range(max(1, args.warmup)):
-            rrt.launch_raymarch(buf, w, h, 1.0, cam, tex, fx, prm_f)
+        legs = {}
+        for name, mode in (("fmad", 2), ("fast", 1)):
+            prm_f = rrt.RenderParams(spin=args.spin, volumetrics=1, arith_mode=mode, noise_table=ntab.id if ntab else 0)
+            for _ in range(max(1, args.warmup)):
+                rrt.launch_raymarch(buf, w, h, 1.0, cam, tex, fx, prm_f)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                rrt.launch_raymarch(buf, w, h, 1.0, cam, tex, fx, prm_f)
+            torch.cuda.synchronize()
+            dtf = time.perf_counter() - t1
+            legs[name] = {"arith_mode": mode, "value": round(w * h * args.steps / dtf / 1e6, 3), "unit": "Mrays/s",
+                          "ms_per_step": round(dtf / args.steps * 1e3, 3), "fps": round(args.steps / dtf, 3)}
+        _, ill, st = conditioning.account(tex, w, h, cam, 1.0, (2, 1), fx=fx, spin=args.spin, volumetrics=1,
+                                          noise_table=ntab.id if ntab else 0)
+        for name, mode in (("fmad", 2), ("fast", 1)):
+            q = st[mode]
+            legs[name]["vs_strict_frame"] = q
+            legs[name]["account_clean"] = (q["outliers_not_ill"] == 0 and q["steps_differ_not_ill"] == 0 and
+                                           q["bytes_off_by_more_than_1_not_ill"] == 0)
+        legs["fmad"]["note"] = ("RRT_ARITH_FMAD: the RK4 step with multiply-adds fused, sqrt and divide correctly rounded "
+                                "(nvcc's defaults for the reference: -fmad=true, IEEE div/sqrt); media, sky, post-FX unchanged")
+        legs["fast"]["note"] = "RRT_ARITH_FAST: fused multiply-adds, 1-ulp v_rsq, no correctly rounded divide in the RK4 step"
+        clean = [n for n in ("fast", "fmad") if legs[n]["account_clean"]]
+        best = max(clean, key=lambda n: legs[n]["fps"]) if clean else None
+        wtol = {"mode": best, "fps": legs[best]["fps"] if best else None, "ms_per_step": legs[best]["ms_per_step"] if best else None,
+                "value": legs[best]["value"] if best else None, "unit": "Mrays/s",
+                "meets_30_fps": bool(best and legs[best]["fps"] >= 30.0),
+                "conditioning": {"pixels": st["pixels"], "ill_conditioned_pixels": st["ill"], "nudged_strict_frames": st["nudged_frames"],
+                                 "pixels_one_nudged_frame_moves_by_K_ulps": st["single_nudge_moves"], "tolerance": st["tolerance"],
+                                 "statement": "every pixel of the mode's frame that is outside the tolerance of the strict frame, takes "
+                                              "another number of steps or has a byte off by more than one LSB is a pixel the STRICT "
+                                              "arithmetic itself moves out of the tolerance (or to another step count) when its primary "
+                                              "direction is nudged by <= 16 ulps (rrt_params.nudge_ulps; *_not_ill counts are 0); "
+                                              "asserted at 1080p and 4K on three views by tests/test_gpu_tolerance.py"},
+                "modes": legs,
+                "note": "never `value`: the headline, its roofline and the bit-parity claims are the strict path's"}
+
+    # The headline frame WITHOUT the lattice-hash tables (every noise3D hashed arithmetically): the tables are a resident
+    # input built outside the timed region, so the line carries the table-free time beside `value`.
+    arith_noise = None
+    if world == 1 and ntab is not None:
+        prm_a = rrt.RenderParams(spin=args.spin, volumetrics=1)
+        abuf = torch.zeros(h * w * 4, dtype=torch.uint8, device=dev)
+        rrt.launch_raymarch(abuf, w, h, 1.0, cam, tex, fx, prm_a)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            rrt.launch_raymarch(buf, w, h, 1.0, cam, tex, fx, prm_f)
+            rrt.launch_raymarch(abuf, w, h, 1.0, cam, tex, fx, prm_a)
         torch.cuda.synchronize()
-        dtf = time.perf_counter() - t1
-        d8 = (buf.view(-1, 4)[:, :3].int() - strict_frame.view(-1, 4)[:, :3].int()).abs()
-        fast = {"value": round(w * h * args.steps / dtf / 1e6, 3), "unit": "Mrays/s",
-                "ms_per_step": round(dtf / args.steps * 1e3, 3), "fps": round(args.steps / dtf, 3),
-                "vs_strict_frame": {"bytes_identical": round(float((d8 == 0).float().mean()), 6),
-                                    "bytes_off_by_more_than_1": int((d8 > 1).sum()), "max_byte_diff": int(d8.max())},
-                "note": "rrt_params.arith_mode=RRT_ARITH_FAST: fused multiply-adds and 1-ulp rsq in the RK4 "
-                        "integrator; informational, not the parity path"}
+        dta = time.perf_counter() - t1
+        arith_noise = {"value": round(w * h * args.steps / dta / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(dta / args.steps * 1e3, 3),
+                       "fps": round(args.steps / dta, 3), "same_bytes_as_headline": bool(torch.equal(abuf, fs.frame.view(-1))),
+                       "note": "rrt_params.noise_table = 0: the same frame with no precomputed input but the sky"}
+        del abuf
 
     # Informational third leg (single GPU): the same launch on a disk-heavy view -- the "Horizon Skimmer" keyframe
     # (camera_paths.cpp:62) from inside the disk, where media sampling is ~40 % of the work -- strict arithmetic,
@@ -526,11 +594,17 @@ def main():
                                  "frac": round(hbm_gbs / HBM_PEAK_GBS, 6),
                                  "note": "algorithmic 52 B/ray; the path is not HBM-bound"}},
             "cpu_baseline": cpu,
-            "fast_mode": fast,
+            "within_tolerance_mode": wtol,
+            "headline_arithmetic_noise": arith_noise,
             "heavy_view": heavy,
         }
         if world > 1:
-            line["multi_gpu"] = {"phases": phases, "one_frame_at_a_time": one_at_a_time,
+            best_single = min(single_ref["static_order_ms"], single_ref["cost_ordered_ms"])
+            line["multi_gpu"] = {"single_gpu_reference_ms": best_single, "single_gpu_reference": single_ref,
+                                 "speedup_vs_single_gpu_reference": round(best_single / ms_per_step, 3),
+                                 "single_gpu_reference_note": "the same frame on rank 0's GPU alone, single kernel, noise tables, best of static and "
+                                                              "cost-ordered dispatch, measured in this run while the other ranks waited",
+                                 "phases": phases, "one_frame_at_a_time": one_at_a_time,
                                  "frames_in_flight": fs.n_slots,
                                  "frames_in_flight_note": "default 3: chosen on ONE GPU rendering a single rank's share "
                                                           "(profiles/r02_frames_in_flight.txt); provisional until a run on >= 2 GPUs"}

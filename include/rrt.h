@@ -36,7 +36,9 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 4      /* 4: rrt_params.struct_size (leading), .pool_rounds, .pass_chains, rrt_tile_map_*, rrt_probe_tile_costs,
+#define RRT_ABI_VERSION 5      /* 5: RRT_ARITH_FMAD, rrt_params.nudge_ulps / .nudge_seed, rrt_params_init (an rrt_params of ABI 4's
+                                     48 bytes is still accepted: the new fields read as 0);
+                                  4: rrt_params.struct_size (leading), .pool_rounds, .pass_chains, rrt_tile_map_*, rrt_probe_tile_costs,
                                      rrt_clock_probe; 3: rrt_params.tile_order, rrt_tile_order_* */
 
 typedef enum {
@@ -78,9 +80,10 @@ typedef struct rrt_effects {
  * (config.h:21) so that Kerr a=0.9 / 0.99 are run-time settings. */
 typedef struct rrt_params {
     uint32_t struct_size;    /* sizeof(rrt_params) of the header the caller was compiled against; rrt_params_default()
-                                fills it in and every entry point that takes an rrt_params refuses another value with
-                                RRT_ERR_ABI_MISMATCH (objects built against the ABI <= 3 header, whose struct began with
-                                `spin`, must be recompiled)                                              */
+                                fills it in.  Every entry point that takes an rrt_params accepts this header's size and
+                                ABI 4's 48 bytes (a prefix: the fields behind it read as their defaults) and refuses any
+                                other value with RRT_ERR_ABI_MISMATCH (objects built against the ABI <= 3 header, whose
+                                struct began with `spin`, must be recompiled)                                */
     float spin;              /* SPIN_A            config.h:21  default 0.0  */
     int32_t max_steps;       /* MAX_STEPS         config.h:48  default 2000 */
     int32_t volumetrics;     /* 1 = full disk + dust (reference behaviour);
@@ -89,10 +92,15 @@ typedef struct rrt_params {
     int32_t sky_frac_bits;   /* bilinear weight bits of the sky sampler:
                                 8 = CUDA-texture-like (default), 0 = exact  */
     int32_t arith_mode;      /* RRT_ARITH_STRICT (default): every operation rounded as the
-                                reference source writes it -- the parity path.
+                                reference source writes it -- the bit-parity path.
+                                RRT_ARITH_FMAD: the geodesic integrator with multiply-adds FUSED and
+                                division / square root still correctly rounded -- the arithmetic class
+                                of the reference's own build (nvcc defaults: -fmad=true, IEEE div/sqrt);
+                                media, sky and post-FX code unchanged.  Within the 1e-4 tolerance of the
+                                strict frame on every pixel whose strict value is itself stable under a
+                                few-ulp nudge of its primary ray (tests/test_gpu_tolerance.py).
                                 RRT_ARITH_FAST: fused multiply-adds and 1-ulp reciprocal
-                                square roots in the geodesic integrator; NOT bit-comparable
-                                with the oracle                      */
+                                square roots, no correctly rounded divide; informational.       */
     int32_t workspace;       /* 0 (default): single kernel, media sampled in line by the marching
                                 lane.  An rrt_workspace id: three-pass path -- the march only
                                 records in-medium sample points, which the whole chip then evaluates
@@ -126,6 +134,13 @@ typedef struct rrt_params {
                                 along its dispatch order and the halves run their march -> evaluate -> composite chains
                                 side by side (the workspace's own second stream), so that one half's evaluation fills the
                                 other half's march tail; 1 = one chain; 2 = two whenever possible.  Same bytes.           */
+    int32_t nudge_ulps;      /* conditioning probe (ABI 5).  0 (default): primary rays exactly as raymarcher.cu:27-34 forms
+                                them.  K > 0: every component of every pixel's normalised primary direction is moved by a
+                                pseudo-random whole number of ulps in [-K, K] (a hash of pixel and nudge_seed; the oracle has
+                                the same function).  Rendering a frame under a few such nudges shows which pixels the
+                                reference's own arithmetic does not determine to the tolerance -- near-critical rays, zone
+                                and density gates about to flip: how the within-tolerance arithmetic modes are accounted for. */
+    uint32_t nudge_seed;
 } rrt_params;
 
 #define RRT_PATH_AUTO 0
@@ -134,6 +149,7 @@ typedef struct rrt_params {
 
 #define RRT_ARITH_STRICT 0
 #define RRT_ARITH_FAST 1
+#define RRT_ARITH_FMAD 2
 
 /* Opaque sky-texture handle; stands in for cudaTextureObject_t
  * (`unsigned long long`, reference src/main.cpp:231-263). */
@@ -159,9 +175,14 @@ int rrt_abi_version(void);
 const char* rrt_status_string(int status);
 const char* rrt_last_hip_error(void);          /* thread-local text of the last HIP failure */
 int rrt_device_count(int* count);
-int rrt_params_default_v4(rrt_params* prm);    /* config.h defaults, struct_size = this header's sizeof(rrt_params) */
-#define rrt_params_default rrt_params_default_v4   /* (the library keeps an export of the old name that fills the 36-byte
-                                                      ABI <= 3 layout, so that a stale binary is refused, not corrupted) */
+/* config.h defaults into the first `size` bytes of an rrt_params and struct_size = size.  Call it through the macro below, so
+ * that `size` is the sizeof of the header the CALLER was compiled against: the library then knows which fields the caller
+ * has.  Accepted sizes: this header's, and ABI 4's 48 bytes (fields the caller does not have read as their defaults); any
+ * other size is RRT_ERR_ABI_MISMATCH here and at every entry point that takes an rrt_params. */
+int rrt_params_init(void* prm, uint32_t size);
+#define rrt_params_default(p) rrt_params_init((p), (uint32_t)sizeof(rrt_params))
+/* (the library also keeps the exports older headers mapped the name to: rrt_params_default_v4 fills ABI 4's 48 bytes -- such a
+ * binary keeps working --, rrt_params_default the 36-byte ABI <= 3 layout, whose binaries are refused at their first launch) */
 int rrt_effects_default(rrt_effects* fx);      /* camera_settings.h:5-16 defaults          */
 
 /* ---- sky texture: replaces loadSkybox()'s cudaMallocArray + texture object,
@@ -254,7 +275,8 @@ int rrt_clock_probe(unsigned long long* d_counters2, unsigned duration_us, void*
  *      no argument for them: spin, max_steps, volumetrics, a workspace, a noise table ...  NULL restores the
  *      config.h defaults.  Nothing is allocated on the caller's behalf: objects named here are the caller's. ---- */
 int rrt_set_launch_defaults(const rrt_params* prm);
-int rrt_get_launch_defaults(rrt_params* out);
+int rrt_get_launch_defaults_sized(void* out, uint32_t size);        /* through the macro: size = the caller's sizeof(rrt_params) */
+#define rrt_get_launch_defaults(out) rrt_get_launch_defaults_sized((out), (uint32_t)sizeof(rrt_params))
 /* launch_raymarch() with plain C types (what both C++ symbols of that name forward to): cam12 = pos, forward,
  * right, up; effects36 = the 36 bytes of struct CameraEffects (== rrt_effects); null stream, asynchronous. */
 int rrt_launch_raymarch_compat(void* d_out_rgba8, int width, int height, float time, const float* cam12,

@@ -41,7 +41,8 @@ class Effects(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("spin", _f), ("volumetrics", C.c_int32), ("max_steps", C.c_int32),
-                ("math_mode", C.c_int32), ("sky_frac_bits", C.c_int32)]
+                ("math_mode", C.c_int32), ("sky_frac_bits", C.c_int32),
+                ("nudge_ulps", C.c_int32), ("nudge_seed", C.c_uint32)]
 
 
 class Diag(C.Structure):

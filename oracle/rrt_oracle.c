@@ -464,6 +464,25 @@ static void trace_pixel_g(const rrto_camera* cam, const rrto_effects* fx, const 
                           float time, int width, int height, int x, int y,
                           const uint8_t* sky, int sw, int sh, pixel_out* o,
                           int gate_mode, uint8_t* gate_log, int gate_cap, int* gate_n);
+static uint32_t nudge_mix(uint32_t v) {
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v;
+}
+/* the bit pattern is stepped as a sign-magnitude integer: a step across zero lands on the small float of the other sign */
+float rrto_nudge_component(float v, int32_t K, uint32_t seed, int32_t x, int32_t y, uint32_t comp) {
+    const uint32_t h = nudge_mix(nudge_mix((uint32_t)x * 0x9e3779b1u + (uint32_t)y) ^ (seed * 0x85ebca6bu + comp * 0xc2b2ae35u));
+    const int32_t k = (int32_t)(h % (uint32_t)(2 * K + 1)) - K;
+    uint32_t b;
+    memcpy(&b, &v, 4);
+    int32_t m = (int32_t)(b & 0x7fffffffu);
+    m = (b >> 31) ? -m : m;
+    m += k;
+    const uint32_t out = m < 0 ? (0x80000000u | (uint32_t)(-m)) : (uint32_t)m;
+    float r;
+    memcpy(&r, &out, 4);
+    return r;
+}
+
 static void trace_pixel(const rrto_camera* cam, const rrto_effects* fx, const rrto_params* prm,
                         float time, int width, int height, int x, int y,
                         const uint8_t* sky, int sw, int sh, pixel_out* o) {
@@ -493,6 +512,11 @@ static void trace_pixel_g(const rrto_camera* cam, const rrto_effects* fx, const 
 
     f3 p = cpos;
     f3 rd = normalize3(add3(cfwd, add3(mul3(crgt, u_coord), mul3(cup, v_coord))));
+    if (prm->nudge_ulps != 0) {          /* conditioning probe: not in the reference (raymarcher.cu:27-34 ends above) */
+        rd.x = rrto_nudge_component(rd.x, prm->nudge_ulps, prm->nudge_seed, x, y, 0u);
+        rd.y = rrto_nudge_component(rd.y, prm->nudge_ulps, prm->nudge_seed, x, y, 1u);
+        rd.z = rrto_nudge_component(rd.z, prm->nudge_ulps, prm->nudge_seed, x, y, 2u);
+    }
     f3 vel = rd;
 
     float intensity_r = 0, intensity_g = 0, intensity_b = 0;
@@ -666,6 +690,7 @@ void rrto_default_params(rrto_params* p) {
     p->max_steps = 2000;       /* config.h:48 */
     p->math_mode = RRTO_MATH_LIBM;
     p->sky_frac_bits = 8;
+    p->nudge_ulps = 0; p->nudge_seed = 0u;
 }
 
 void rrto_default_effects(rrto_effects* e) {   /* camera_settings.h:5-16 */

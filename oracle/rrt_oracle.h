@@ -67,7 +67,14 @@ typedef struct {
     int32_t max_steps;       /* MAX_STEPS, config.h:48 */
     int32_t math_mode;       /* RRTO_MATH_* */
     int32_t sky_frac_bits;   /* bilinear weight quantisation; 0 = none, 8 = CUDA-like */
+    int32_t nudge_ulps;      /* conditioning probe (no counterpart in the reference): K > 0 moves every component of every
+                                primary direction by a pseudo-random whole number of ulps in [-K, K]; the product's
+                                rrt_params.nudge_ulps / .nudge_seed is the same function (rrto_nudge_component) */
+    uint32_t nudge_seed;
 } rrto_params;
+
+/* v moved by k ulps, k in [-K, K] from a hash of (x, y, seed, component 0..2) */
+float rrto_nudge_component(float v, int32_t K, uint32_t seed, int32_t x, int32_t y, uint32_t comp);
 
 typedef struct {             /* per-ray diagnostics, all optional */
     int32_t* steps;          /* loop iterations executed (RK4 steps taken) */

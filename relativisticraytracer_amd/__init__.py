@@ -115,7 +115,7 @@ class RenderParams(rrt_params):
 
     def __init__(self, **kw):
         super().__init__()
-        _lib.check(_lib.load().rrt_params_default_v4(C.byref(self)), "rrt_params_default")
+        _lib.check(_lib.load().rrt_params_init(C.byref(self), C.sizeof(rrt_params)), "rrt_params_init")
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError(k)
@@ -425,7 +425,7 @@ def set_launch_defaults(params):
 
 def get_launch_defaults():
     out = RenderParams()
-    _lib.check(_lib.load().rrt_get_launch_defaults(C.byref(out)), "rrt_get_launch_defaults")
+    _lib.check(_lib.load().rrt_get_launch_defaults_sized(C.byref(out), C.sizeof(rrt_params)), "rrt_get_launch_defaults")
     return out
 
 

@@ -40,7 +40,8 @@ class rrt_params(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("spin", C.c_float), ("max_steps", C.c_int32), ("volumetrics", C.c_int32),
                 ("sky_frac_bits", C.c_int32), ("arith_mode", C.c_int32), ("workspace", C.c_int32),
                 ("path_policy", C.c_int32), ("noise_table", C.c_int32), ("tile_order", C.c_int32),
-                ("pool_rounds", C.c_int32), ("pass_chains", C.c_int32)]
+                ("pool_rounds", C.c_int32), ("pass_chains", C.c_int32),
+                ("nudge_ulps", C.c_int32), ("nudge_seed", C.c_uint32)]
 
 
 class rrt_debug_outputs(C.Structure):
@@ -57,7 +58,7 @@ SYMBOLS = [
     ("rrt_status_string", C.c_char_p, [_i]),
     ("rrt_last_hip_error", C.c_char_p, []),
     ("rrt_device_count", _i, [C.POINTER(_i)]),
-    ("rrt_params_default_v4", _i, [_prm]),
+    ("rrt_params_init", _i, [_vp, C.c_uint32]),
     ("rrt_effects_default", _i, [_fx]),
     ("rrt_sky_create", _i, [_vp, _i, _i, C.POINTER(_ull)]),
     ("rrt_sky_create_from_device", _i, [_vp, _i, _i, C.POINTER(_ull)]),
@@ -88,7 +89,7 @@ SYMBOLS = [
     ("rrt_noise_table_fit_window", _i, [_f, _f, C.c_size_t, C.POINTER(_f), C.POINTER(_i), C.POINTER(C.c_size_t)]),
     ("rrt_debug_fake_device", _i, [_i]),
     ("rrt_set_launch_defaults", _i, [_prm]),
-    ("rrt_get_launch_defaults", _i, [_prm]),
+    ("rrt_get_launch_defaults_sized", _i, [_vp, C.c_uint32]),
     ("rrt_launch_raymarch_compat", _i, [_vp, _i, _i, _f, C.POINTER(C.c_float * 12), _ull, _vp]),
     ("rrt_workspace_stats", _i, [_i, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     ("rrt_workspace_read", _i, [_i, C.c_size_t, C.c_size_t, _vp]),

@@ -17,7 +17,7 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "librrt_hip.so")
 SOURCES = [os.path.join(CSRC, "rrt_hip.hip")]
 COMPAT_SRC = os.path.join(CSRC, "rrt_compat.cpp")     # launch_raymarch under the reference's mangled name (host only, g++)
-HEADERS = [os.path.join(CSRC, "rrt_device.h"), os.path.join(CSRC, "rrt_math.h"), COMPAT_SRC,
+HEADERS = [os.path.join(CSRC, "rrt_device.h"), os.path.join(CSRC, "rrt_math.h"), os.path.join(CSRC, "rrt_tile_sort.h"), COMPAT_SRC,
            os.path.join(PKG, "..", "include", "rrt.h"), os.path.join(PKG, "..", "include", "raymarcher.h")]
 
 # -ffp-contract=off: the kernels' arithmetic contract (csrc/rrt_device.h).

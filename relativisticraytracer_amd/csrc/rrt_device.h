@@ -566,12 +566,24 @@ RRT_DEV unsigned long long stage_radius_yh(float r2, float y0, float h0, float& 
     return small_mask;
 }
 
+/* fused forms of the 3-vector helpers (RRT_ARITH_FMAD / RRT_ARITH_FAST): one rounding per multiply-add */
+RRT_DEV float dot_fma(v3 a, v3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+RRT_DEV v3 axpy(v3 x, float a, v3 y) {       /* a*x + y, fused */
+    return mk(__builtin_fmaf(x.x, a, y.x), __builtin_fmaf(x.y, a, y.y), __builtin_fmaf(x.z, a, y.z));
+}
+RRT_DEV v3 cross_fma(v3 a, v3 b) {
+    return mk(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+
 /* geodesic_acc_r without the guard; lanes in `small_mask` (only ever set behind radius_fallback) get the zero of
- * geodesics.h:33.  The mask is a scalar: the straight path pays one s_cmp, no vector instruction. */
-template <bool SPIN>
+ * geodesics.h:33.  The mask is a scalar: the straight path pays one s_cmp, no vector instruction.
+ * FMA (RRT_ARITH_FMAD): the same expression tree with every multiply-add fused -- cross and dot products, the drag term --
+ * and the two divisions still correctly rounded (div_seeded): what a contracting compiler with IEEE division makes of
+ * geodesics.h:30-45 (nvcc's defaults for the reference: -fmad=true, -prec-div=true, -prec-sqrt=true). */
+template <bool SPIN, bool FMA = false>
 RRT_DEV v3 geodesic_acc_ng(v3 p, v3 v, float drag_c, float r2, float r, float y, unsigned long long small_mask) {
-    v3 L = cross(p, v);
-    float L2 = dot(L, L);
+    v3 L = FMA ? cross_fma(p, v) : cross(p, v);
+    float L2 = FMA ? dot_fma(L, L) : dot(L, L);
     float y2 = y * y;
     float y3 = y2 * y;
     float d2 = r2 * r;
@@ -580,8 +592,13 @@ RRT_DEV v3 geodesic_acc_ng(v3 p, v3 v, float drag_c, float r2, float r, float y,
     v3 acc = mul(p, radial_mag);
     if (SPIN) {
         float ds = div_seeded(drag_c, d2, y3);
-        acc.x = acc.x + p.z * ds;
-        acc.z = acc.z + (-p.x) * ds;
+        if (FMA) {
+            acc.x = __builtin_fmaf(p.z, ds, acc.x);
+            acc.z = __builtin_fmaf(-p.x, ds, acc.z);
+        } else {
+            acc.x = acc.x + p.z * ds;
+            acc.z = acc.z + (-p.x) * ds;
+        }
     }
     if (__builtin_expect(small_mask != 0ull, 0)) {
         if ((small_mask >> (threadIdx.x & 63)) & 1ull) acc = mk(0.f, 0.f, 0.f);
@@ -604,8 +621,12 @@ RRT_DEV v3 geodesic_acc_ng(v3 p, v3 v, float drag_c, float r2, float r, float y,
  * Sign: the acceptance test is even in the seed (a seed of MINUS the reciprocal root converges to minus the root with a
  * zero residual), so seeds must be positive by provenance -- they are: every h is either the v_rsq fall-back's or
  * h0 (1 + r) of an accepted root with |r| <= 9e-3, i.e. positive by induction, and an extrapolated 2 h_a - h_b of two
- * such values could only be negative if the radius had tripled within half a vacuum step (0.15 |v| at r >= 30). */
-template <bool SPIN, bool VAC>
+ * such values could only be negative if the radius had tripled within half a vacuum step (0.15 |v| at r >= 30).
+ * FMA (RRT_ARITH_FMAD, round 5): stage states, squared radii and the final combination as fused multiply-adds (one rounding
+ * where the source has two); roots and divisions exactly as in the strict step -- correctly rounded.  ~223 instead of ~283
+ * VALU instructions per vacuum step.  Not bit-comparable with the strict step (every fused product skips a rounding), which
+ * is the arithmetic the reference's own binary has under nvcc's default -fmad=true. */
+template <bool SPIN, bool VAC, bool FMA = false>
 RRT_DEV void integrate_rk4_lean(v3& p, v3& v, float h_in, float hh_in, float h6_in, float drag_c,
                                 float r2, float r, float y, float hy, float& y_next, float& h_next, float& hc_prev) {
     const float h = VAC ? kStepSize : h_in;
@@ -613,10 +634,10 @@ RRT_DEV void integrate_rk4_lean(v3& p, v3& v, float h_in, float hh_in, float h6_
     const float h6 = VAC ? kStepSize / 6.0f : h6_in;
     constexpr bool EXTRAP = VAC && RRT_EXTRAP_SEEDS;
     v3 p0 = p, v0 = v;
-    v3 kv1 = geodesic_acc_ng<SPIN>(p0, v0, drag_c, r2, r, y, 0ull);
-    v3 v2 = add(v0, mul(kv1, hh));
-    v3 p2 = add(p0, mul(v0, hh));
-    float r2b = dot(p2, p2), rb, yb, hb;
+    v3 kv1 = geodesic_acc_ng<SPIN, FMA>(p0, v0, drag_c, r2, r, y, 0ull);
+    v3 v2 = FMA ? axpy(kv1, hh, v0) : add(v0, mul(kv1, hh));
+    v3 p2 = FMA ? axpy(v0, hh, p0) : add(p0, mul(v0, hh));
+    float r2b = FMA ? dot_fma(p2, p2) : dot(p2, p2), rb, yb, hb;
     unsigned long long sb;
     if (EXTRAP) {
         const float h0 = __builtin_fmaf(2.0f, hy, -hc_prev);
@@ -624,15 +645,15 @@ RRT_DEV void integrate_rk4_lean(v3& p, v3& v, float h_in, float hh_in, float h6_
     } else {
         sb = stage_radius_yh<2>(r2b, y, hy, rb, yb, hb);
     }
-    v3 kv2 = geodesic_acc_ng<SPIN>(p2, v2, drag_c, r2b, rb, yb, sb);
-    v3 v3_ = add(v0, mul(kv2, hh));
-    v3 p3 = add(p0, mul(v2, hh));
-    float r2c = dot(p3, p3), rc, yc, hc;
+    v3 kv2 = geodesic_acc_ng<SPIN, FMA>(p2, v2, drag_c, r2b, rb, yb, sb);
+    v3 v3_ = FMA ? axpy(kv2, hh, v0) : add(v0, mul(kv2, hh));
+    v3 p3 = FMA ? axpy(v2, hh, p0) : add(p0, mul(v2, hh));
+    float r2c = FMA ? dot_fma(p3, p3) : dot(p3, p3), rc, yc, hc;
     const unsigned long long sc = stage_radius_yh<1>(r2c, yb, hb, rc, yc, hc);
-    v3 kv3 = geodesic_acc_ng<SPIN>(p3, v3_, drag_c, r2c, rc, yc, sc);
-    v3 v4 = add(v0, mul(kv3, h));
-    v3 p4 = add(p0, mul(v3_, h));
-    float r2d = dot(p4, p4), rd, yd, hd;
+    v3 kv3 = geodesic_acc_ng<SPIN, FMA>(p3, v3_, drag_c, r2c, rc, yc, sc);
+    v3 v4 = FMA ? axpy(kv3, h, v0) : add(v0, mul(kv3, h));
+    v3 p4 = FMA ? axpy(v3_, h, p0) : add(p0, mul(v3_, h));
+    float r2d = FMA ? dot_fma(p4, p4) : dot(p4, p4), rd, yd, hd;
     unsigned long long sd;
     if (EXTRAP) {
         const float h0 = __builtin_fmaf(2.0f, hc, -hy);
@@ -641,7 +662,7 @@ RRT_DEV void integrate_rk4_lean(v3& p, v3& v, float h_in, float hh_in, float h6_
         sd = stage_radius_yh<2>(r2d, yc, hc, rd, yd, hd);
     }
     hc_prev = VAC ? hc : 0.0f;            /* a generic step has another spacing: no extrapolation across it */
-    v3 kv4 = geodesic_acc_ng<SPIN>(p4, v4, drag_c, r2d, rd, yd, sd);
+    v3 kv4 = geodesic_acc_ng<SPIN, FMA>(p4, v4, drag_c, r2d, rd, yd, sd);
     v3 kv_sum, kp_sum;
     kv_sum.x = kv1.x + __builtin_fmaf(2.0f, kv2.x, __builtin_fmaf(2.0f, kv3.x, kv4.x));
     kv_sum.y = kv1.y + __builtin_fmaf(2.0f, kv2.y, __builtin_fmaf(2.0f, kv3.y, kv4.y));
@@ -649,8 +670,8 @@ RRT_DEV void integrate_rk4_lean(v3& p, v3& v, float h_in, float hh_in, float h6_
     kp_sum.x = v0.x + __builtin_fmaf(2.0f, v2.x, __builtin_fmaf(2.0f, v3_.x, v4.x));
     kp_sum.y = v0.y + __builtin_fmaf(2.0f, v2.y, __builtin_fmaf(2.0f, v3_.y, v4.y));
     kp_sum.z = v0.z + __builtin_fmaf(2.0f, v2.z, __builtin_fmaf(2.0f, v3_.z, v4.z));
-    v = add(v0, mul(kv_sum, h6));
-    p = add(p0, mul(kp_sum, h6));
+    v = FMA ? axpy(kv_sum, h6, v0) : add(v0, mul(kv_sum, h6));
+    p = FMA ? axpy(kp_sum, h6, p0) : add(p0, mul(kp_sum, h6));
     y_next = yd;
     h_next = hd;
 }
@@ -681,11 +702,6 @@ RRT_DEV v3 geodesic_acc_fast(v3 p, v3 v, float drag_c, float r2, float y) {
         if (r2 < 1.0f) acc = mk(0.f, 0.f, 0.f);
     }
     return acc;
-}
-
-RRT_DEV float dot_fma(v3 a, v3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
-RRT_DEV v3 axpy(v3 x, float a, v3 y) {       /* a*x + y, fused */
-    return mk(__builtin_fmaf(x.x, a, y.x), __builtin_fmaf(x.y, a, y.y), __builtin_fmaf(x.z, a, y.z));
 }
 
 template <bool SPIN>

@@ -20,7 +20,6 @@
  *   C ABI of include/rrt.h, sky and workspace registries, camera basis / path playback
  */
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>        /* DeviceRadixSort for rrt_tile_order */
 
 #include <atomic>
 #include <memory>
@@ -36,6 +35,7 @@
 
 #include "../../include/rrt.h"
 #include "rrt_device.h"
+#include "rrt_tile_sort.h"              /* the native radix sort behind rrt_tile_order */
 
 namespace {
 
@@ -341,6 +341,7 @@ struct FrameArgs {
     /* params */
     float spin, drag_c;
     int max_steps;
+    int nudge_ulps; unsigned nudge_seed;      /* rrt_params.nudge_ulps / .nudge_seed: the conditioning probe (primary_ray) */
     RowMap rows;
     rrt_debug_outputs dbg;
     /* deferred-sampling workspace (three-pass path), all NULL for the single-kernel path */
@@ -385,16 +386,16 @@ std::shared_ptr<TileMapObject> tile_map_lookup(int id) {
  * static order (row blocks from the middle outwards) is right for the reference's default view and wrong wherever the
  * longest rays are somewhere else: from inside the disk a 4K frame spends 8 % of its time draining.
  * An rrt_tile_order object remembers, per wave tile, the clocks the previous launch through it took, and dispatches the
- * next launch of the same geometry longest-first (one radix sort of n_tiles keys after the frame, ~20 us).  Any order
+ * next launch of the same geometry longest-first (one radix sort of n_tiles keys after the frame, ~20 us: rrt_tile_sort.h).  Any order
  * renders the same pixels.  All launches through one object are serialised on the device (an event chains them across
  * streams): frames that should overlap need an object each. */
 struct TileOrderObject {
     int device;
     unsigned* d_cost;        /* clocks >> 4 of each wave tile, written by the render kernel */
-    unsigned* d_sorted;      /* the sort's key output (unused) */
-    unsigned* d_iota;        /* 0 .. n_cap-1 */
+    unsigned* d_sorted;      /* the sort's keys between its two passes (before the sort: scratch of the cost probe) */
+    unsigned* d_iota;        /* ... and the tiles that travel with them */
     unsigned* d_perm[2];     /* dispatch slot -> wave tile; [cur] is the one the next matching launch reads */
-    void* d_temp; size_t temp_bytes;
+    void* d_temp; size_t temp_bytes;      /* the sort's (digit, block) counters (rrt_tile_sort.h) */
     size_t n_cap;
     int cur;
     bool have;               /* d_perm[cur] holds an order for the geometry below */
@@ -421,11 +422,6 @@ std::shared_ptr<TileOrderObject> tile_order_lookup(int id) {
     return it == g_to.end() ? nullptr : it->second;
 }
 
-__global__ __launch_bounds__(256) void fill_iota(unsigned* v, unsigned n) {
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) v[i] = i;
-}
-
 /* image row of local row `lr`, and the local output row it is stored at */
 __device__ __forceinline__ bool map_row(const RowMap& m, int height, int lr, int& y, int& out_row) {
     if (lr >= m.n_local_rows) return false;
@@ -438,6 +434,23 @@ __device__ __forceinline__ bool map_row(const RowMap& m, int height, int lr, int
     int rows_k = min(m.tile_rows, height - ty0);
     out_row = k * m.tile_rows + (rows_k - 1 - rr);     /* each tile bottom-up, raymarcher.cu:168 */
     return true;
+}
+
+/* v moved by k ulps, k uniform in [-K, K] from a 32-bit mix of (x, y, seed, component).  The bit pattern is stepped as a
+ * sign-magnitude integer, so a step across zero lands on the small float of the other sign; never used on non-finite v. */
+__device__ __forceinline__ uint32_t nudge_mix(uint32_t v) {
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v;
+}
+__device__ __forceinline__ float nudge_component(float v, int K, unsigned seed, int x, int y, unsigned comp) {
+    const uint32_t h = nudge_mix(nudge_mix((uint32_t)x * 0x9e3779b1u + (uint32_t)y) ^ (seed * 0x85ebca6bu + comp * 0xc2b2ae35u));
+    const int k = (int)(h % (uint32_t)(2 * K + 1)) - K;
+    const uint32_t b = rrt_f2u(v);
+    int m = (int)(b & 0x7fffffffu);                  /* magnitude as an integer; sign apart */
+    m = (b >> 31) ? -m : m;
+    m += k;
+    const uint32_t out = m < 0 ? (0x80000000u | (uint32_t)(-m)) : (uint32_t)m;
+    return rrt_u2f(out);
 }
 
 /* Primary ray of pixel (x, y): raymarcher.cu:20-34 (+ lens distortion, post_processing.h:19-24). */
@@ -454,6 +467,13 @@ __device__ __forceinline__ void primary_ray(const FrameArgs& a, int x, int y, fl
     const v3 cup = mk(a.cam.up[0], a.cam.up[1], a.cam.up[2]);
     p = mk(a.cam.pos[0], a.cam.pos[1], a.cam.pos[2]);
     vel = normalize(add(cfw, add(mul(crt, u_coord), mul(cup, v_coord))));
+    if (__builtin_expect(a.nudge_ulps != 0, 0)) {
+        /* conditioning probe (rrt_params.nudge_ulps; oracle: rrto_nudge_direction, the same function): every component of
+         * the unit direction moves by a whole number of ulps in [-K, K] drawn from a hash of (x, y, seed, component) */
+        vel.x = nudge_component(vel.x, a.nudge_ulps, a.nudge_seed, x, y, 0u);
+        vel.y = nudge_component(vel.y, a.nudge_ulps, a.nudge_seed, x, y, 1u);
+        vel.z = nudge_component(vel.z, a.nudge_ulps, a.nudge_seed, x, y, 2u);
+    }
 }
 
 /* Everything after the march: sky, composition, post-FX, tone map, RGBA8 store -- raymarcher.cu:124-173. */
@@ -535,15 +555,17 @@ constexpr float kHVac = kStepSize, kHNear = kStepSize * 0.1f, kHDisk = kStepSize
  * A 256-thread workgroup covers a 16x16 pixel block as four 8x8 wave tiles so that the 64 rays of a
  * wavefront stay spatially coherent (similar step counts, similar zone entry).
  */
-/* radius of the pre-step position exactly as the march sees it (strict: correctly rounded; fast: r2*rsq) */
-template <bool FAST>
+/* radius of the pre-step position exactly as the march sees it (strict: correctly rounded root of the unfused r2; FMAD: the
+ * correctly rounded root of the fused r2; fast: r2*rsq) */
+constexpr int kArithStrict = RRT_ARITH_STRICT, kArithFast = RRT_ARITH_FAST, kArithFmad = RRT_ARITH_FMAD;
+template <int ARITH>
 __device__ __forceinline__ void march_radius(v3 rel_p, float& r2, float& r, float& y) {
-    if (FAST) {
+    if (ARITH == kArithFast) {
         r2 = dot_fma(rel_p, rel_p);
         y = __builtin_amdgcn_rsqf(r2);
         r = r2 * y;
     } else {
-        r2 = dot(rel_p, rel_p);
+        r2 = ARITH == kArithFmad ? dot_fma(rel_p, rel_p) : dot(rel_p, rel_p);
         sqrt_rsq(r2, r, y);
     }
     if (__builtin_expect(__any(!(r2 >= 1.0f)), 0)) {
@@ -626,18 +648,19 @@ __device__ __forceinline__ void march_inline_v1(const FrameArgs& a, v3& p, v3& v
     i = steps;
 }
 
-template <bool SPIN, int MEDIA, bool FAST>
+template <bool SPIN, int MEDIA, int ARITH>
 __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel, Radiance& acc, bool& hit, int& i,
                                              unsigned* oob) {
-    if constexpr (FAST || !RRT_MARCH_V2) {
-        march_inline_v1<SPIN, MEDIA, FAST>(a, p, vel, acc, hit, i, oob);
+    constexpr bool FMA = ARITH == kArithFmad;           /* the lean loop with fused multiply-adds (rrt_device.h: integrate_rk4_lean) */
+    if constexpr (ARITH == kArithFast || !RRT_MARCH_V2) {
+        march_inline_v1<SPIN, MEDIA, ARITH == kArithFast>(a, p, vel, acc, hit, i, oob);
     } else {
         int steps = i > a.max_steps ? i : a.max_steps;  /* if the loop runs out */
         float ys = 0.0f, hs = 0.0f;                     /* (1/r, 1/(2r)) estimate for the next loop-top radius; 0: none yet */
         float hcp = 0.0f;                               /* 1/(2r) at the previous vacuum step's stage 3 (seed extrapolation) */
         for (int k = i; k < a.max_steps; ++k) {
             const v3 rel_p = p;                         /* p - MASS_POS, MASS_POS = 0 */
-            const float r2 = dot(rel_p, rel_p);
+            const float r2 = FMA ? dot_fma(rel_p, rel_p) : dot(rel_p, rel_p);
             float r, y, hy;
             const bool rejected = sqrt_seeded_yh<1>(r2, ys, hs, r, y, hy);
             /* wave-uniform: every live lane holds an accepted radius >= kVacuumR (two compares, scalar logic) */
@@ -645,7 +668,7 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
             const bool vacuum = RRT_VACUUM_PATH && (rej_mask | __builtin_amdgcn_ballot_w64(!(r >= kVacuumR))) == 0ull;
 #if RRT_HORIZON_IN_GENERIC
             if (vacuum) {
-                integrate_rk4_lean<SPIN, true>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, y, hy, ys, hs, hcp);
+                integrate_rk4_lean<SPIN, true, FMA>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, y, hy, ys, hs, hcp);
             } else {
                 if (rej_mask != 0ull) {
                     bool small;
@@ -660,7 +683,7 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
             if (r < kEventHorizon * 1.01f) { hit = true; acc.t = 0.0f; steps = k; break; }
 
             if (vacuum) {
-                integrate_rk4_lean<SPIN, true>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, y, hy, ys, hs, hcp);
+                integrate_rk4_lean<SPIN, true, FMA>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, y, hy, ys, hs, hcp);
             } else {
 #endif
                 const bool near_bh = r < 18.0f;
@@ -668,14 +691,14 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
                 const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
                 float h, hh, h6;
                 zone_step(near_bh, in_disk, h, hh, h6);
-                integrate_rk4_lean<SPIN, false>(p, vel, h, hh, h6, a.drag_c, r2, r, y, hy, ys, hs, hcp);
+                integrate_rk4_lean<SPIN, false, FMA>(p, vel, h, hh, h6, a.drag_c, r2, r, y, hy, ys, hs, hcp);
                 if (MEDIA != 0 && (in_disk || in_cloud)) {
                     float d_disk, d_cloud;
                     media_densities<MEDIA == 2>(rel_p, a.time, in_disk, in_cloud, a.lut_acc, a.lut_dust, oob, d_disk, d_cloud);
                     accumulate_sample(acc, d_disk, d_cloud, rel_p, r, vel, h, a.spin);
                 }
             }
-            if (r > 250.0f && dot(rel_p, vel) > 0.0f) { steps = k + 1; break; }     /* raymarcher.cu:120 */
+            if (r > 250.0f && (FMA ? dot_fma(rel_p, vel) : dot(rel_p, vel)) > 0.0f) { steps = k + 1; break; }     /* raymarcher.cu:120 */
         }
         i = steps;
     }
@@ -730,6 +753,7 @@ __device__ __forceinline__ int tile_column(const FrameArgs& a) {
  * needs bits 6..21 of it (0.5 us steps), which is what the radix sort looks at: two 8-bit passes. */
 constexpr unsigned kTileCostMax = (1u << 22) - 1u;
 constexpr int kTileCostSortLo = 6, kTileCostSortHi = 22;
+static_assert(kTileCostSortHi - kTileCostSortLo == 16 && (kTileCostMax >> kTileCostSortHi) == 0u, "rrt_tile_sort.h sorts 16 key bits in two passes");
 
 /* the wave tile (row_block * gridDim.x + column) this workgroup renders: the static order above, or the launch's
  * cost-ordered permutation */
@@ -783,7 +807,7 @@ __device__ __forceinline__ void add_tile_cost(const FrameArgs& a, unsigned long 
 #ifndef RRT_MEDIA_WAVES
 #define RRT_MEDIA_WAVES 5
 #endif
-template <bool SPIN, int MEDIA, bool DEBUG, bool FAST>
+template <bool SPIN, int MEDIA, bool DEBUG, int ARITH>
 __global__ __launch_bounds__(kWGThreads, (MEDIA != 0 && !DEBUG ? RRT_MEDIA_WAVES : 1))      /* 2nd: minimum waves per SIMD */
 void raymarch_pixels(const FrameArgs a) {
 #if defined(RRT_OCC_PROBE_LDS)      /* dev probe: cap the occupancy of the kernel WITHOUT media code through its LDS footprint (8192 B per one-wave
@@ -800,7 +824,7 @@ void raymarch_pixels(const FrameArgs a) {
     Radiance acc = {0.f, 0.f, 0.f, 1.0f};
     bool hit = false;
     int i = 0;
-    march_inline<SPIN, MEDIA, FAST>(a, p, vel, acc, hit, i, DEBUG ? a.dbg.d_lut_oob : nullptr);
+    march_inline<SPIN, MEDIA, ARITH>(a, p, vel, acc, hit, i, DEBUG ? a.dbg.d_lut_oob : nullptr);
     shade_and_store<DEBUG>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, i);
     if (a.tile_cost) {          /* what this wave cost, for the next launch's order (every lane stores the same word) */
         const unsigned long long dt = (__builtin_readcyclecounter() - t_start) >> 4;
@@ -821,8 +845,9 @@ void raymarch_pixels(const FrameArgs a) {
 #else
 #define RRT_DEFER_SGPR_ATTR
 #endif
-template <bool SPIN, bool FAST, bool RESUME>
+template <bool SPIN, int ARITH, bool RESUME>
 __global__ __launch_bounds__(kWGThreads, RRT_DEFER_WAVES) RRT_DEFER_SGPR_ATTR void march_defer(const FrameArgs a) {
+    constexpr bool FAST = ARITH == kArithFast, FMA = ARITH == kArithFmad;
     if (RESUME && a.ctr->last_overflow == 0u) return;            /* nothing was suspended: the whole grid leaves at once */
 #ifdef RRT_WAVE_TIMELINE
     const unsigned long long t_start = a.tile_cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -867,7 +892,7 @@ __global__ __launch_bounds__(kWGThreads, RRT_DEFER_WAVES) RRT_DEFER_SGPR_ATTR vo
         float r2, r, yv, hv = 0.0f;
         bool vacuum = false;
         if constexpr (LEAN) {
-            r2 = dot(rel_p, rel_p);
+            r2 = FMA ? dot_fma(rel_p, rel_p) : dot(rel_p, rel_p);
             const bool rejected = sqrt_seeded_yh<1>(r2, y_seed, h_seed, r, yv, hv);
             const unsigned long long rej_mask = __builtin_amdgcn_ballot_w64(rejected);
             vacuum = RRT_VACUUM_PATH && (rej_mask | __builtin_amdgcn_ballot_w64(!(r >= kVacuumR))) == 0ull;
@@ -876,7 +901,7 @@ __global__ __launch_bounds__(kWGThreads, RRT_DEFER_WAVES) RRT_DEFER_SGPR_ATTR vo
                 if (rejected) radius_fallback(r2, r, yv, hv, small);
             }
         } else if (RRT_SEEDED_SQRT) march_radius_seeded<FAST>(rel_p, y_seed, r2, r, yv);
-        else march_radius<FAST>(rel_p, r2, r, yv);
+        else march_radius<ARITH>(rel_p, r2, r, yv);
         if (r < kEventHorizon * 1.01f) { hit = true; break; }
 
         bool in_disk = false, in_cloud = false;
@@ -960,15 +985,15 @@ __global__ __launch_bounds__(kWGThreads, RRT_DEFER_WAVES) RRT_DEFER_SGPR_ATTR vo
         }
 
         if constexpr (LEAN) {
-            if (vacuum) integrate_rk4_lean<SPIN, true>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, yv, hv, y_seed, h_seed, hc_prev);
-            else integrate_rk4_lean<SPIN, false>(p, vel, h, hh, h6, a.drag_c, r2, r, yv, hv, y_seed, h_seed, hc_prev);
+            if (vacuum) integrate_rk4_lean<SPIN, true, FMA>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, yv, hv, y_seed, h_seed, hc_prev);
+            else integrate_rk4_lean<SPIN, false, FMA>(p, vel, h, hh, h6, a.drag_c, r2, r, yv, hv, y_seed, h_seed, hc_prev);
         } else march_step<SPIN, FAST>(p, vel, h, hh, h6, a.drag_c, r2, r, yv, y_seed);
 
         if (!vacuum && need) {                                                /* pre-step position, post-step velocity */
             row_f[0] = rel_p.x; row_f[64] = rel_p.y; row_f[128] = rel_p.z;
             row_f[192] = vel.x; row_f[256] = vel.y; row_f[320] = vel.z;
         }
-        if (r > 250.0f && dot(rel_p, vel) > 0.0f) { ++i; break; }
+        if (r > 250.0f && (FMA ? dot_fma(rel_p, vel) : dot(rel_p, vel)) > 0.0f) { ++i; break; }
     }
 
     /* wave-level epilogue: all 64 lanes are here */
@@ -1015,7 +1040,7 @@ __global__ void pool_next_round(DeferCounters* c, unsigned capacity, int last) {
 }
 
 /* ---- pass 2: densities + emission of every pooled sample row, grid-stride over the pool ---- */
-template <bool FAST, bool LUT>
+template <int ARITH, bool LUT>
 __global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
     const int lane = threadIdx.x & 63;
     const unsigned n_blk = min(a.ctr->next_block, a.block_capacity);
@@ -1030,7 +1055,7 @@ __global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
         const v3 rel_p = mk(f[0], f[64], f[128]);
         const v3 vel = mk(f[192], f[256], f[320]);
         float r2, r, yv;
-        march_radius<FAST>(rel_p, r2, r, yv);
+        march_radius<ARITH>(rel_p, r2, r, yv);
         const bool near_bh = r < 18.0f;
         const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
         const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
@@ -1047,7 +1072,7 @@ __global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
 
 /* ---- pass 3: composite each ray's samples in march order; shade the rays of wavefronts that have reached their end;
  *      LAST (the last round the host enqueued): rays still suspended are finished with the media sampled in line ---- */
-template <bool SPIN, bool FAST, bool LUT, bool LAST>
+template <bool SPIN, int ARITH, bool LUT, bool LAST>
 __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArgs a) {
     if (a.ctr->rounds_run != 0u && a.ctr->last_overflow == 0u) return;      /* a later round with nothing left: all leave */
     const unsigned long long t_start = a.tile_cost ? __builtin_readcyclecounter() : 0ull;
@@ -1121,7 +1146,7 @@ __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArg
         /* the pool ran out under this ray at step `steps` and no round is left: carry on from its saved pre-step state
          * with the media sampled in line -- the samples composited above come first, exactly as in the single kernel */
         p = mk(a.finals[4 * a.n_lanes + li], a.finals[5 * a.n_lanes + li], a.finals[6 * a.n_lanes + li]);
-        march_inline<SPIN, LUT ? 2 : 1, FAST>(a, p, vel, acc, hit, steps, nullptr);
+        march_inline<SPIN, LUT ? 2 : 1, ARITH>(a, p, vel, acc, hit, steps, nullptr);
     }
     if (hit) acc.t = 0.0f;                                         /* raymarcher.cu:49 */
     shade_and_store<false>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, steps);
@@ -1444,7 +1469,7 @@ __global__ void k_rt_sample(int n, const float* d_disk, const float* d_cloud, co
     if (i >= n) return;
     const v3 rp = ld3(p, i);
     float r2, r, y;
-    march_radius<false>(rp, r2, r, y);
+    march_radius<kArithStrict>(rp, r2, r, y);
     Radiance acc = {rad[4 * i], rad[4 * i + 1], rad[4 * i + 2], rad[4 * i + 3]};
     accumulate_sample(acc, d_disk[i], d_cloud[i], rp, r, ld3(vel, i), h[i], spin);
     rad[4 * i] = acc.r; rad[4 * i + 1] = acc.g; rad[4 * i + 2] = acc.b; rad[4 * i + 3] = acc.t;
@@ -1695,24 +1720,37 @@ __global__ void k_selfcheck_div_const(uint32_t lo, uint32_t hi, unsigned long lo
 }
 
 /* ------------------------------------------------------------------ host helpers */
-/* an rrt_params built against another header is refused before any field of it is believed */
+/* an rrt_params built against another header is refused before any field of it is believed -- except ABI 4's 48-byte
+ * layout, a strict prefix of this one: its caller simply has no nudge fields (they read as 0) */
+constexpr uint32_t kParamsSizeAbi4 = 48;
+static_assert(sizeof(rrt_params) == 56 && offsetof(rrt_params, nudge_ulps) == kParamsSizeAbi4, "rrt_params layout (ABI 5)");
 int check_params_abi(const rrt_params* prm) {
-    if (prm && prm->struct_size != (uint32_t)sizeof(rrt_params)) {
-        snprintf(g_hip_err, sizeof(g_hip_err), "rrt_params.struct_size %u, this library's is %zu (ABI %d): recompile against include/rrt.h",
-                 prm->struct_size, sizeof(rrt_params), RRT_ABI_VERSION);
+    if (prm && prm->struct_size != (uint32_t)sizeof(rrt_params) && prm->struct_size != kParamsSizeAbi4) {
+        snprintf(g_hip_err, sizeof(g_hip_err), "rrt_params.struct_size %u, this library's is %zu (ABI %d; ABI 4's %u is accepted too): recompile against include/rrt.h",
+                 prm->struct_size, sizeof(rrt_params), RRT_ABI_VERSION, kParamsSizeAbi4);
         return RRT_ERR_ABI_MISMATCH;
     }
     return RRT_OK;
 }
-int check_params_values(const rrt_params* prm) {
+/* the caller's struct (NULL: config.h defaults) as this library's layout; check_params_abi() has passed */
+void load_params(const rrt_params* in, rrt_params& out) {
+    rrt_params_init(&out, (uint32_t)sizeof(out));
+    if (in) memcpy(&out, in, in->struct_size < sizeof(out) ? in->struct_size : sizeof(out));
+    out.struct_size = (uint32_t)sizeof(out);
+}
+int check_params_values(const rrt_params* prm_in) {
+    rrt_params full;
+    load_params(prm_in, full);
+    const rrt_params* prm = &full;
     if (prm->max_steps < 0 || prm->sky_frac_bits < 0 || prm->sky_frac_bits > 16) return RRT_ERR_INVALID_ARGUMENT;
     if (!(prm->spin == prm->spin)) return RRT_ERR_INVALID_ARGUMENT;
-    if (prm->arith_mode != RRT_ARITH_STRICT && prm->arith_mode != RRT_ARITH_FAST) return RRT_ERR_INVALID_ARGUMENT;
+    if (prm->arith_mode != RRT_ARITH_STRICT && prm->arith_mode != RRT_ARITH_FAST && prm->arith_mode != RRT_ARITH_FMAD) return RRT_ERR_INVALID_ARGUMENT;
     if (prm->workspace < 0) return RRT_ERR_INVALID_ARGUMENT;
     if (prm->path_policy < RRT_PATH_AUTO || prm->path_policy > RRT_PATH_THREE_PASS) return RRT_ERR_INVALID_ARGUMENT;
     if (prm->noise_table < 0 || prm->tile_order < 0) return RRT_ERR_INVALID_ARGUMENT;
     if (prm->pool_rounds < 0 || prm->pool_rounds > 64) return RRT_ERR_INVALID_ARGUMENT;
     if (prm->pass_chains < 0 || prm->pass_chains > kMaxChains) return RRT_ERR_INVALID_ARGUMENT;
+    if (prm->nudge_ulps < 0 || prm->nudge_ulps > 4096) return RRT_ERR_INVALID_ARGUMENT;
     return RRT_OK;
 }
 int check_common(const void* out, int width, int height, const rrt_camera* cam, const rrt_effects* fx,
@@ -1728,12 +1766,12 @@ int check_common(const void* out, int width, int height, const rrt_camera* cam, 
     return RRT_OK;
 }
 
-struct LaunchOpts { int media; bool fast; int workspace, policy, pool_rounds, pass_chains; };
+struct LaunchOpts { int media; int arith; int workspace, policy, pool_rounds, pass_chains; };
 
 int fill_args(FrameArgs& a, LaunchOpts& o, void* out, int width, int height, float time, const rrt_camera* cam,
               rrt_sky_t sky, const rrt_effects* fx, const rrt_params* prm_in) {
     rrt_params prm;
-    if (prm_in) prm = *prm_in; else rrt_params_default(&prm);
+    load_params(prm_in, prm);
     SkyObject so;
     if (!sky_lookup(sky, so) || !on_current_device(so.device)) return RRT_ERR_BAD_HANDLE;
     const SkyObject* s = &so;
@@ -1748,6 +1786,7 @@ int fill_args(FrameArgs& a, LaunchOpts& o, void* out, int width, int height, flo
     a.spin = prm.spin;
     a.drag_c = (2.0f * prm.spin) * 2.0f;            /* 2.0f * SPIN_A * EVENT_HORIZON, geodesics.h:41 */
     a.max_steps = prm.max_steps;
+    a.nudge_ulps = prm.nudge_ulps; a.nudge_seed = prm.nudge_seed;
     memset(&a.dbg, 0, sizeof(a.dbg));
     a.tile_perm = nullptr; a.tile_cost = nullptr; a.tile_order_id = prm.tile_order;
     a.grid_rows = 0; a.grid_row_base = 0;
@@ -1773,7 +1812,7 @@ int fill_args(FrameArgs& a, LaunchOpts& o, void* out, int width, int height, flo
             a.lut_dust = make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust, nt.dust_families);
         }
     }
-    o.fast = prm.arith_mode == RRT_ARITH_FAST;
+    o.arith = prm.arith_mode;
     o.workspace = prm.workspace;
     o.policy = prm.path_policy;
     o.pool_rounds = prm.pool_rounds;
@@ -1809,29 +1848,24 @@ int auto_pool_rounds(const volatile DeferCounters* h, unsigned capacity) {
 
 /* one chain = march -> evaluate -> composite (in rounds) over dispatch rows [row0, row1) of the launch, in its own slice
  * of the pool, on its own stream */
-int enqueue_chain(FrameArgs a, bool fast, bool lut, dim3 full_grid, int row0, int row1, int rounds, hipStream_t st) {
-    if (row1 <= row0) return RRT_OK;
-    const dim3 block(kWGThreads), grid(full_grid.x, (unsigned)(row1 - row0));
-    a.grid_rows = (int)full_grid.y; a.grid_row_base = row0;
+/* the kernels of one arithmetic mode, instantiated per (spin, tables) */
+template <int ARITH>
+int enqueue_chain_arith(const FrameArgs& a, bool lut, dim3 grid, dim3 block, int rounds, hipStream_t st) {
     const bool spin = a.spin != 0.0f;
     for (int r = 0; r < rounds; ++r) {
         const bool last = r == rounds - 1;
-#define RRT_MARCH(S, F) do { if (r == 0) hipLaunchKernelGGL((march_defer<S, F, false>), grid, block, 0, st, a); \
-                             else hipLaunchKernelGGL((march_defer<S, F, true>), grid, block, 0, st, a); } while (0)
-        if (spin) { if (fast) RRT_MARCH(true, true); else RRT_MARCH(true, false); }
-        else      { if (fast) RRT_MARCH(false, true); else RRT_MARCH(false, false); }
+#define RRT_MARCH(S) do { if (r == 0) hipLaunchKernelGGL((march_defer<S, ARITH, false>), grid, block, 0, st, a); \
+                          else hipLaunchKernelGGL((march_defer<S, ARITH, true>), grid, block, 0, st, a); } while (0)
+        if (spin) RRT_MARCH(true); else RRT_MARCH(false);
 #undef RRT_MARCH
         RRT_HIP(hipGetLastError());
-#define RRT_EVAL(F, L) hipLaunchKernelGGL((eval_sample_rows<F, L>), dim3(2048), dim3(256), 0, st, a)
-        if (fast) { if (lut) RRT_EVAL(true, true); else RRT_EVAL(true, false); }
-        else      { if (lut) RRT_EVAL(false, true); else RRT_EVAL(false, false); }
-#undef RRT_EVAL
+        if (lut) hipLaunchKernelGGL((eval_sample_rows<ARITH, true>), dim3(2048), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((eval_sample_rows<ARITH, false>), dim3(2048), dim3(256), 0, st, a);
         RRT_HIP(hipGetLastError());
-#define RRT_COMP3(S, F, L) do { if (last) hipLaunchKernelGGL((composite_and_shade<S, F, L, true>), grid, block, 0, st, a); \
-                                else hipLaunchKernelGGL((composite_and_shade<S, F, L, false>), grid, block, 0, st, a); } while (0)
-#define RRT_COMP(S, F) do { if (lut) RRT_COMP3(S, F, true); else RRT_COMP3(S, F, false); } while (0)
-        if (spin) { if (fast) RRT_COMP(true, true); else RRT_COMP(true, false); }
-        else      { if (fast) RRT_COMP(false, true); else RRT_COMP(false, false); }
+#define RRT_COMP3(S, L) do { if (last) hipLaunchKernelGGL((composite_and_shade<S, ARITH, L, true>), grid, block, 0, st, a); \
+                             else hipLaunchKernelGGL((composite_and_shade<S, ARITH, L, false>), grid, block, 0, st, a); } while (0)
+#define RRT_COMP(S) do { if (lut) RRT_COMP3(S, true); else RRT_COMP3(S, false); } while (0)
+        if (spin) RRT_COMP(true); else RRT_COMP(false);
 #undef RRT_COMP
 #undef RRT_COMP3
         RRT_HIP(hipGetLastError());
@@ -1839,6 +1873,17 @@ int enqueue_chain(FrameArgs a, bool fast, bool lut, dim3 full_grid, int row0, in
         RRT_HIP(hipGetLastError());
     }
     return RRT_OK;
+}
+
+/* one chain = march -> evaluate -> composite (in rounds) over dispatch rows [row0, row1) of the launch, in its own slice
+ * of the pool, on its own stream */
+int enqueue_chain(FrameArgs a, int arith, bool lut, dim3 full_grid, int row0, int row1, int rounds, hipStream_t st) {
+    if (row1 <= row0) return RRT_OK;
+    const dim3 block(kWGThreads), grid(full_grid.x, (unsigned)(row1 - row0));
+    a.grid_rows = (int)full_grid.y; a.grid_row_base = row0;
+    if (arith == kArithFast) return enqueue_chain_arith<kArithFast>(a, lut, grid, block, rounds, st);
+    if (arith == kArithFmad) return enqueue_chain_arith<kArithFmad>(a, lut, grid, block, rounds, st);
+    return enqueue_chain_arith<kArithStrict>(a, lut, grid, block, rounds, st);
 }
 
 /* Three-pass launch through a workspace.  Returns RRT_OK after enqueuing, or -1 if the workspace cannot
@@ -1854,7 +1899,7 @@ int enqueue_chain(FrameArgs a, bool fast, bool lut, dim3 full_grid, int row0, in
  * other.  Same kernels, same arithmetic, same bytes; an eighth of the bench frame 5.7 -> 5.2 ms, of the view from inside
  * the disk 12.4 -> 9.5 ms (profiles/r04_split_chain_probe.txt).  The side stream and its events belong to the workspace;
  * a launch that is being captured into a graph, or a small one, runs one chain. */
-int launch_deferred(FrameArgs a, bool fast, bool lut, const WorkspaceObject& ws, int pool_rounds, int chains_wanted, hipStream_t st) {
+int launch_deferred(FrameArgs a, int arith, bool lut, const WorkspaceObject& ws, int pool_rounds, int chains_wanted, hipStream_t st) {
     dim3 grid((a.width + kWGPixX - 1) / kWGPixX, (a.rows.n_local_rows + kWGPixY - 1) / kWGPixY);
     const size_t n_waves = (size_t)grid.x * grid.y * kWGWaves;
     const size_t n_lanes = n_waves * 64;
@@ -1907,7 +1952,7 @@ int launch_deferred(FrameArgs a, bool fast, bool lut, const WorkspaceObject& ws,
         b.block_capacity = (unsigned)cap_of[c];
         const int rounds = pool_rounds > 0 ? pool_rounds : auto_pool_rounds(ws.h_stats ? ws.h_stats + c : nullptr, b.block_capacity);
         const hipStream_t cs = c == 1 ? ws.side : st;
-        const int rc = enqueue_chain(b, fast, lut, grid, row0, row_end[c], rounds, cs);
+        const int rc = enqueue_chain(b, arith, lut, grid, row0, row_end[c], rounds, cs);
         if (rc != RRT_OK) return rc;
         /* what this chain needed, for the next launch's round count and pool split (and rrt_workspace_stats) */
         if (ws.h_stats) RRT_HIP(hipMemcpyAsync(ws.h_stats + c, b.ctr, sizeof(DeferCounters), hipMemcpyDeviceToHost, cs));
@@ -1943,14 +1988,10 @@ int tile_order_reserve(TileOrderObject& o, size_t n) {
         hipError_t e = hipMalloc(reinterpret_cast<void**>(b), cap * sizeof(unsigned));
         if (e != hipSuccess) return hip_fail(e, "hipMalloc(tile order)");
     }
-    size_t tb = 0;
-    RRT_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, o.d_cost, o.d_sorted, o.d_iota, o.d_perm[0], (int)cap, kTileCostSortLo, kTileCostSortHi, nullptr));
-    hipError_t e = hipMalloc(&o.d_temp, tb > 0 ? tb : 16);
+    const size_t tb = (size_t)2 * 256 * rrt_sort::kMaxBlocks * sizeof(unsigned);      /* counters for any n (2 MB) */
+    hipError_t e = hipMalloc(&o.d_temp, tb);
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(tile order sort)");
     o.temp_bytes = tb;
-    fill_iota<<<dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, nullptr>>>(o.d_iota, (unsigned)cap);
-    RRT_HIP(hipGetLastError());
-    RRT_HIP(hipDeviceSynchronize());
     o.n_cap = cap;
     return RRT_OK;
 }
@@ -2024,30 +2065,33 @@ int launch(const FrameArgs& a, const LaunchOpts& o, bool debug, hipStream_t st) 
                 hipLaunchKernelGGL(probe_to_tiles, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, order->d_cost, grid.x, grid.y, q);
                 RRT_HIP(hipGetLastError());
                 const int next = order->cur ^ 1;
-                size_t tb = order->temp_bytes;
-                RRT_HIP(hipcub::DeviceRadixSort::SortPairsDescending(order->d_temp, tb, order->d_cost, order->d_sorted, order->d_iota,
-                                                                     order->d_perm[next], (int)n_tiles, kTileCostSortLo, kTileCostSortHi, st));
+                RRT_HIP(rrt_sort::enqueue(order->d_cost, order->d_sorted, order->d_iota, static_cast<unsigned*>(order->d_temp),
+                                          order->d_perm[next], n_tiles, grid.x, grid.y, kTileCostSortLo, st));
                 order->cur = next;
                 ++order->seeded;
             }
             const bool ordered = same || !order->no_seed;
             b.tile_perm = ordered ? order->d_perm[order->cur] : nullptr;
             b.tile_cost = order->d_cost;
+            /* the one hipMemsetAsync on a launch path.  Safe where the workspace header's was not (zero_words, above): this
+             * branch is only entered when `st` is NOT being captured -- a captured launch ignores the tile-order object -- so the
+             * memset is never turned into a graph node that a replay would have to re-execute */
             RRT_HIP(hipMemsetAsync(order->d_cost, 0, n_tiles * sizeof(unsigned), st));
             if (same) ++order->ordered;
         }
     }
     bool launched = false;
     if (deferred) {
-        const int rc = launch_deferred(b, o.fast, o.media == 2, ws, o.pool_rounds, o.pass_chains, st);
+        const int rc = launch_deferred(b, o.arith, o.media == 2, ws, o.pool_rounds, o.pass_chains, st);
         if (rc > 0) return rc;
         launched = rc == RRT_OK;
     }
     if (!launched) {
         const int media = o.media;
-        const bool fast = o.fast;
+        const int arith = o.arith;
 #define RRT_LAUNCH4(S, M, D, F) hipLaunchKernelGGL((raymarch_pixels<S, M, D, F>), grid, block, 0, st, b)
-#define RRT_LAUNCH3(S, M, D) do { if (fast) RRT_LAUNCH4(S, M, D, true); else RRT_LAUNCH4(S, M, D, false); } while (0)
+#define RRT_LAUNCH3(S, M, D) do { if (arith == kArithFast) RRT_LAUNCH4(S, M, D, kArithFast); else if (arith == kArithFmad) RRT_LAUNCH4(S, M, D, kArithFmad); \
+                                  else RRT_LAUNCH4(S, M, D, kArithStrict); } while (0)
 #define RRT_LAUNCH2(S, M) do { if (debug) RRT_LAUNCH3(S, M, true); else RRT_LAUNCH3(S, M, false); } while (0)
 #define RRT_LAUNCH1(S) do { if (media == 2) RRT_LAUNCH2(S, 2); else if (media == 1) RRT_LAUNCH2(S, 1); else RRT_LAUNCH2(S, 0); } while (0)
         if (spin) RRT_LAUNCH1(true); else RRT_LAUNCH1(false);
@@ -2059,9 +2103,8 @@ int launch(const FrameArgs& a, const LaunchOpts& o, bool debug, hipStream_t st) 
     }
     if (order) {
         const int next = order->cur ^ 1;
-        size_t tb = order->temp_bytes;
-        RRT_HIP(hipcub::DeviceRadixSort::SortPairsDescending(order->d_temp, tb, order->d_cost, order->d_sorted, order->d_iota,
-                                                             order->d_perm[next], (int)n_tiles, kTileCostSortLo, kTileCostSortHi, st));
+        RRT_HIP(rrt_sort::enqueue(order->d_cost, order->d_sorted, order->d_iota, static_cast<unsigned*>(order->d_temp),
+                                  order->d_perm[next], n_tiles, grid.x, grid.y, kTileCostSortLo, st));
         RRT_HIP(hipEventRecord(order->chained, st));
         order->cur = next; order->have = true; ++order->launches;
         order->grid_x = grid.x; order->grid_y = grid.y; order->width = a.width; order->height = a.height; order->rows = a.rows;
@@ -2116,21 +2159,29 @@ int rrt_device_count(int* count) {
     return n > 0 ? RRT_OK : RRT_ERR_NO_DEVICE;
 }
 
-int rrt_params_default_v4(rrt_params* p) {
+int rrt_params_init(void* p, uint32_t size) {
     if (!p) return RRT_ERR_INVALID_ARGUMENT;
-    memset(p, 0, sizeof(*p));
-    p->struct_size = (uint32_t)sizeof(*p);
-    p->spin = 0.0f;          /* SPIN_A    config.h:21 */
-    p->max_steps = 2000;     /* MAX_STEPS config.h:48 */
-    p->volumetrics = 1;
-    p->sky_frac_bits = 8;
+    if (size != (uint32_t)sizeof(rrt_params) && size != kParamsSizeAbi4) return RRT_ERR_ABI_MISMATCH;
+    rrt_params d;
+    memset(&d, 0, sizeof(d));
+    d.spin = 0.0f;          /* SPIN_A    config.h:21 */
+    d.max_steps = 2000;     /* MAX_STEPS config.h:48 */
+    d.volumetrics = 1;
+    d.sky_frac_bits = 8;
+    d.struct_size = size;
+    memcpy(p, &d, size);
     return RRT_OK;
 }
 
-/* The symbol binaries built against the ABI <= 3 header call (include/rrt.h now maps the name to rrt_params_default_v4):
- * it fills the 36 bytes THEIR struct has -- spin, max_steps, volumetrics, sky_frac_bits, arith_mode, workspace,
- * path_policy, noise_table, tile_order -- and not a byte more, so such a binary is refused at its first launch
- * (RRT_ERR_ABI_MISMATCH: its first word is `spin`, not a struct size) instead of having its stack overwritten here. */
+/* what binaries built against the ABI 4 header call: that header's struct is the first 48 bytes of today's, and such a
+ * struct is still accepted by every entry point (check_params_abi) */
+int rrt_params_default_v4(void* abi4_48) { return rrt_params_init(abi4_48, kParamsSizeAbi4); }
+
+/* The symbol binaries built against the ABI <= 3 header call: it fills the 36 bytes THEIR struct has -- spin, max_steps,
+ * volumetrics, sky_frac_bits, arith_mode, workspace, path_policy, noise_table, tile_order -- and not a byte more, so such
+ * a binary is refused at its first launch (RRT_ERR_ABI_MISMATCH: its first word is `spin`, not a struct size) instead of
+ * having its stack overwritten here. */
+#pragma push_macro("rrt_params_default")
 #undef rrt_params_default
 int rrt_params_default(void* legacy36) {
     if (!legacy36) return RRT_ERR_INVALID_ARGUMENT;
@@ -2138,7 +2189,7 @@ int rrt_params_default(void* legacy36) {
     memcpy(legacy36, w, sizeof(w));
     return RRT_OK;
 }
-#define rrt_params_default rrt_params_default_v4
+#pragma pop_macro("rrt_params_default")
 
 int rrt_effects_default(rrt_effects* e) {    /* camera_settings.h:5-16 */
     if (!e) return RRT_ERR_INVALID_ARGUMENT;
@@ -2302,17 +2353,25 @@ int rrt_set_launch_defaults(const rrt_params* prm) {
     int rc = check_params_abi(prm);
     if (rc == RRT_OK) rc = check_params_values(prm);
     if (rc != RRT_OK) return rc;
-    g_defaults = *prm;
+    load_params(prm, g_defaults);
     g_defaults_set = true;
     return RRT_OK;
 }
 
-int rrt_get_launch_defaults(rrt_params* out) {
+int rrt_get_launch_defaults_sized(void* out, uint32_t size) {
     if (!out) return RRT_ERR_INVALID_ARGUMENT;
+    if (size != (uint32_t)sizeof(rrt_params) && size != kParamsSizeAbi4) return RRT_ERR_ABI_MISMATCH;
     std::lock_guard<std::mutex> lk(g_defaults_mu);
-    if (g_defaults_set) { *out = g_defaults; return RRT_OK; }
-    return rrt_params_default(out);
+    if (!g_defaults_set) return rrt_params_init(out, size);
+    memcpy(out, &g_defaults, size);
+    static_cast<rrt_params*>(out)->struct_size = size;
+    return RRT_OK;
 }
+/* the export ABI 4 binaries call: their struct has 48 bytes */
+#pragma push_macro("rrt_get_launch_defaults")
+#undef rrt_get_launch_defaults
+int rrt_get_launch_defaults(void* abi4_48) { return rrt_get_launch_defaults_sized(abi4_48, kParamsSizeAbi4); }
+#pragma pop_macro("rrt_get_launch_defaults")
 
 /* launch_raymarch() as the reference spells it, minus the C++ types: cam12 = pos, forward, right, up;
  * effects36 = the 36 bytes of struct CameraEffects.  Asynchronous on the null stream.  The reference's
@@ -2738,7 +2797,7 @@ int rrt_probe_tile_costs(int width, int height, int tile_rows, float time, const
     if (n_tiles != (height + tile_rows - 1) / tile_rows) return RRT_ERR_INVALID_ARGUMENT;
     if (prm) { int rc = check_params_abi(prm); if (rc == RRT_OK) rc = check_params_values(prm); if (rc != RRT_OK) return rc; }
     rrt_params p;
-    if (prm) p = *prm; else rrt_params_default(&p);
+    load_params(prm, p);
     FrameArgs a;
     memset(&a, 0, sizeof(a));
     a.width = width; a.height = height; a.time = time; a.cam = *cam;

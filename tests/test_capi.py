@@ -12,6 +12,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 def declared_functions():
     src = open(os.path.join(ROOT, "include", "rrt.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"^[ \t]*#[ \t]*define[^\n]*(\\\n[^\n]*)*", "", src, flags=re.M)      # macros (rrt_params_default -> rrt_params_init) are not symbols
     return sorted(set(re.findall(r"\b(rrt_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -26,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.rrt_abi_version() == 4
+    assert lib.rrt_abi_version() == 5
 
 
 def test_library_exports_launch_raymarch_as_a_cpp_symbol():
@@ -174,7 +175,7 @@ def test_struct_layouts_match_the_reference_structs():
     assert [offs[k] for k in ("use_bloom", "bloom_threshold", "bloom_intensity", "use_vignette",
                               "vignette_intensity", "use_chromatic_aberration", "ca_amount",
                               "use_lens_distortion", "distortion_amount")] == [0, 4, 8, 12, 16, 20, 24, 28, 32]
-    assert C.sizeof(_lib.rrt_params) == 48          # ABI 4: struct_size first, pool_rounds / pass_chains last
+    assert C.sizeof(_lib.rrt_params) == 56          # ABI 5: struct_size first, nudge_ulps / nudge_seed last (ABI 4: 48, ended with pass_chains)
     assert _lib.rrt_params.struct_size.offset == 0 and _lib.rrt_params.spin.offset == 4
 
 
@@ -196,7 +197,7 @@ def test_status_strings_and_host_side_errors():
     lib = _lib.load()
     assert lib.rrt_status_string(0) == b"ok"
     assert lib.rrt_status_string(1) == b"invalid argument"
-    assert lib.rrt_params_default_v4(None) == 1
+    assert lib.rrt_params_init(None, 56) == 1
     assert lib.rrt_effects_default(None) == 1
     assert lib.rrt_sky_destroy(0) == 4
     assert lib.rrt_sky_create(None, 4, 4, None) == 1
@@ -226,7 +227,7 @@ def test_tile_order_argument_checks_need_no_gpu():
     from relativisticraytracer_amd import _lib
     lib = _lib.load()
     prm = _lib.rrt_params()
-    assert lib.rrt_params_default_v4(C.byref(prm)) == 0
+    assert lib.rrt_params_init(C.byref(prm), C.sizeof(_lib.rrt_params)) == 0
     assert prm.tile_order == 0 and prm.struct_size == C.sizeof(_lib.rrt_params)
     prm.tile_order = -1
     assert lib.rrt_set_launch_defaults(C.byref(prm)) == 1          # RRT_ERR_INVALID_ARGUMENT
@@ -236,19 +237,40 @@ def test_tile_order_argument_checks_need_no_gpu():
 
 
 def test_params_from_another_abi_are_refused_not_believed():
-    """ABI 4: rrt_params leads with its own size.  A struct of another size -- a binary built against the
-    ABI <= 3 header, whose struct began with `spin` -- is RRT_ERR_ABI_MISMATCH at every entry point that takes one, and the
-    symbol such a binary calls for its defaults still exists and writes the 36 bytes ITS struct has, not one more."""
+    """rrt_params leads with its own size (ABI 4).  ABI 5 appended two fields: this header's 56 bytes and ABI 4's
+    48 -- a strict prefix, whose missing fields read as their defaults -- are accepted; a struct of any other size -- a binary
+    built against the ABI <= 3 header, whose struct began with `spin` -- is RRT_ERR_ABI_MISMATCH at every entry point that
+    takes one, and the symbols older binaries call for their defaults still exist and write the bytes THEIR struct has, not
+    one more."""
     import ctypes as C
     import numpy as np
     from relativisticraytracer_amd import _lib
     lib = _lib.load()
+    assert lib.rrt_abi_version() == 5 and C.sizeof(_lib.rrt_params) == 56
     prm = _lib.rrt_params()
-    assert lib.rrt_params_default_v4(C.byref(prm)) == 0 and prm.struct_size == 48 and prm.pool_rounds == 0 and prm.pass_chains == 0
+    assert lib.rrt_params_init(C.byref(prm), 56) == 0 and prm.struct_size == 56 and prm.pool_rounds == 0 and prm.pass_chains == 0
+    assert prm.nudge_ulps == 0 and prm.nudge_seed == 0 and prm.max_steps == 2000 and prm.sky_frac_bits == 8
     assert lib.rrt_set_launch_defaults(C.byref(prm)) == 0
+    assert lib.rrt_params_init(C.byref(prm), 52) == 6                # a size no header ever had
     prm.struct_size = 36
     assert lib.rrt_set_launch_defaults(C.byref(prm)) == 6           # RRT_ERR_ABI_MISMATCH
     assert b"ABI" in lib.rrt_status_string(6)
+    assert lib.rrt_set_launch_defaults(None) == 0
+    # the ABI 4 export: 48 bytes, guard bytes behind them untouched; what it wrote is ACCEPTED (nudge fields read as 0)
+    v4 = lib.rrt_params_default_v4
+    v4.restype, v4.argtypes = C.c_int, [C.c_void_p]
+    buf = np.full(64, 0xAB, np.uint8)
+    assert v4(buf.ctypes.data) == 0
+    assert np.array_equal(buf[:48].view(np.int32), [48, 0, 2000, 1, 8, 0, 0, 0, 0, 0, 0, 0]) and np.all(buf[48:] == 0xAB)
+    buf[4:8] = np.frombuffer(np.float32(0.9).tobytes(), np.uint8)    # an ABI 4 caller sets spin ...
+    assert lib.rrt_set_launch_defaults(C.cast(buf.ctypes.data, C.POINTER(_lib.rrt_params))) == 0
+    got = _lib.rrt_params()
+    assert lib.rrt_get_launch_defaults_sized(C.byref(got), 56) == 0
+    assert got.struct_size == 56 and abs(got.spin - 0.9) < 1e-7 and got.nudge_ulps == 0 and got.nudge_seed == 0   # ... the 0xAB behind its struct was not believed
+    g4 = lib.rrt_get_launch_defaults                                 # what an ABI 4 binary calls: writes 48 bytes
+    g4.restype, g4.argtypes = C.c_int, [C.c_void_p]
+    buf2 = np.full(64, 0xCD, np.uint8)
+    assert g4(buf2.ctypes.data) == 0 and buf2[:4].view(np.uint32)[0] == 48 and np.all(buf2[48:] == 0xCD)
     assert lib.rrt_set_launch_defaults(None) == 0
     # the legacy export: 36 bytes, guard bytes behind them untouched
     legacy = lib.rrt_params_default
@@ -256,11 +278,18 @@ def test_params_from_another_abi_are_refused_not_believed():
     buf = np.full(64, 0xAB, np.uint8)
     assert legacy(buf.ctypes.data) == 0
     assert np.array_equal(buf[:36].view(np.int32), [0, 2000, 1, 8, 0, 0, 0, 0, 0]) and np.all(buf[36:] == 0xAB)
-    # ... and what it wrote is refused as an ABI-4 struct (first word = spin bits = 0, not a size)
+    # ... and what it wrote is refused (first word = spin bits = 0, not a size)
     old = (C.c_uint8 * 64).from_buffer_copy(buf.tobytes())
     assert lib.rrt_set_launch_defaults(C.cast(old, C.POINTER(_lib.rrt_params))) == 6
-    prm.struct_size = 48; prm.pool_rounds = -1
+    prm.struct_size = 56; prm.pool_rounds = -1
     assert lib.rrt_set_launch_defaults(C.byref(prm)) == 1
+    prm.pool_rounds = 0; prm.nudge_ulps = -1
+    assert lib.rrt_set_launch_defaults(C.byref(prm)) == 1
+    prm.nudge_ulps = 0; prm.arith_mode = 2
+    assert lib.rrt_set_launch_defaults(C.byref(prm)) == 0           # RRT_ARITH_FMAD
+    prm.arith_mode = 3
+    assert lib.rrt_set_launch_defaults(C.byref(prm)) == 1
+    assert lib.rrt_set_launch_defaults(None) == 0
 
 
 def test_tile_map_balance_is_deterministic_host_arithmetic():

@@ -212,54 +212,30 @@ def test_row_and_tile_shards_reassemble_to_the_full_frame(ctx):
     assert sum(rrt.tile_shard_rows(h, 8, s, 3) for s in range(3)) == h
 
 
+@pytest.mark.parametrize("mode", [2, 1], ids=["fmad", "fast"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_fast_mode_within_tolerance_of_libm_oracle(ctx, frames_gold, name):
-    """RRT_ARITH_FAST against the INDEPENDENT oracle (glibc math, strict IEEE), same bars as the strict
-    path's tolerance test above: float RGB within 1e-4 relative (+1e-5 abs) on >= 99.5 % of pixels."""
-    r, _ = _render(ctx, name, arith_mode=1)
+def test_tolerance_modes_against_the_libm_oracle(ctx, frames_gold, name, mode):
+    """RRT_ARITH_FMAD / RRT_ARITH_FAST against the INDEPENDENT oracle (glibc math, strict IEEE) on the fixtures, at the
+    bars of the strict path's own tolerance test above, set to the measured class (round 5; was >= 99.5 % of pixels): float
+    RGB within 1e-4 relative (+1e-5 abs) on all but a handful of a fixture's pixels, step counts likewise.  The pixel-by-pixel
+    account of what falls outside -- every such pixel is one the strict arithmetic itself does not pin -- is
+    tests/test_gpu_tolerance.py, at 1080p and 4K."""
+    r, _ = _render(ctx, name, arith_mode=mode)
     du8 = np.abs(r["rgba8"].astype(int) - frames_gold[f"{name}_libm_rgba8"].astype(int))
-    same_steps = (r["steps"] == frames_gold[f"{name}_libm_steps"].astype(np.int32)).mean()
-    msg = f"{name}: u8 identical {(du8 == 0).mean():.5f} max {du8.max()} steps identical {same_steps:.5f}"
+    n_px = du8.shape[0] * du8.shape[1]
+    steps_off = int((r["steps"] != frames_gold[f"{name}_libm_steps"].astype(np.int32)).sum())
+    msg = f"{name} mode {mode}: bytes differing {(du8 > 0).sum()} (> 1 LSB: {(du8 > 1).sum()}, max {du8.max()}), step counts differing {steps_off} of {n_px}"
     if name != "G1":
         ref = frames_gold[f"{name}_libm_ldr"][..., :3]
         got = r["ldr"][..., :3]
-        ok = np.abs(got - ref) <= 1e-4 * np.abs(ref) + 1e-5
-        msg += f" within-1e-4 {ok.mean():.5f} max abs {np.abs(got - ref).max():.2e}"
+        bad = (np.abs(got - ref) > 1e-4 * np.abs(ref) + 1e-5).any(axis=2)
+        msg += f", pixels outside 1e-4: {int(bad.sum())}, max abs {np.abs(got - ref).max():.2e}"
         print(msg)
-        assert ok.mean() >= 0.995
-        assert np.abs(got - ref).max() <= 5e-3
+        assert bad.sum() <= 2, msg                       # of 2 304 pixels; measured: 0 on every fixture, both modes
     else:
         print(msg)
-    assert (du8 > 1).mean() <= 0.001
-    assert (du8 > 0).mean() <= 0.01
-    assert same_steps >= 0.995
-
-
-def test_fast_mode_statistics(ctx):
-    """RRT_ARITH_FAST is NOT the parity path: it perturbs every RK4 step at the 1e-7 level (FMA, rsq).
-    This test pins how far it drifts from the strict path on the bench view, so the number quoted in
-    DESIGN.md stays honest: most pixels keep their bytes, nearly all stay within 1 LSB."""
-    import torch
-    g, rrt, tex = ctx
-    w, h = 480, 270
-    cam = rrt.CameraState.default(); fx = rrt.CameraEffects()
-    res = {}
-    for mode in (0, 1):
-        prm = rrt.RenderParams(spin=0.9, arith_mode=mode)
-        out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
-        ldr = torch.zeros(h * w * 4, device="cuda")
-        steps = torch.zeros(h * w, dtype=torch.int32, device="cuda")
-        rrt.launch_raymarch_debug(out, w, h, 1.0, cam, tex, fx, prm, ldr=ldr, steps=steps)
-        torch.cuda.synchronize()
-        res[mode] = (out.cpu().numpy().astype(int), ldr.cpu().numpy().reshape(-1, 4)[:, :3], steps.cpu().numpy())
-    d8 = np.abs(res[0][0] - res[1][0])
-    rel_ok = np.abs(res[0][1] - res[1][1]) <= 1e-4 * np.abs(res[0][1]) + 1e-5
-    print(f"fast vs strict: bytes identical {(d8 == 0).mean():.6f}, <=1 LSB {(d8 <= 1).mean():.6f}, "
-          f"max {d8.max()}, float RGB within 1e-4 rel {rel_ok.mean():.6f}, "
-          f"steps identical {(res[0][2] == res[1][2]).mean():.4f}")
-    assert (d8 == 0).mean() >= 0.90
-    assert (d8 <= 1).mean() >= 0.985
-    assert rel_ok.mean() >= 0.80
+    assert (du8 > 1).sum() <= 2 and (du8 > 0).sum() <= 12, msg      # measured: 0 / <= 4 bytes (G1, 65 536 bytes)
+    assert steps_off <= 3, msg                                       # measured: <= 1 ray per fixture
 
 
 def test_three_pass_workspace_path_is_byte_identical(ctx):
@@ -1166,6 +1142,14 @@ def test_cost_ordered_dispatch_renders_the_same_frames(ctx):
                 perm, cost = info["perm"], info["cost"]
                 assert np.array_equal(np.sort(perm), np.arange(n_tiles, dtype=np.uint32))            # a permutation ...
                 assert np.all(np.diff((cost[perm] >> 6).astype(np.int64)) <= 0) and cost.max() > 0     # ... longest first (in 0.5 us steps)
+                # ... and exactly what a stable sort of the 16 key bits over the STATIC dispatch order gives (round 5, csrc/rrt_tile_sort.h:
+                # tiles of equal cost keep the centre-out order of the static launch)
+                gx, gy = (w + 7) // 8, (h + 7) // 8
+                j = np.arange(gy); mid = (gy - 1) >> 1
+                rb = np.where(j & 1, mid + ((j + 1) >> 1), mid - (j >> 1))
+                static = (rb[:, None] * gx + np.arange(gx)[None, :]).reshape(-1)
+                keys = (cost[static] >> 6) & 0xffff
+                assert np.array_equal(perm, static[np.argsort(-keys.astype(np.int64), kind="stable")])
         # another geometry: ordered by the coarse probe (round 4; no history to go by), and the object starts over
         w2, h2 = 333, 130
         ref2 = torch.zeros(h2 * w2 * 4, dtype=torch.uint8, device="cuda"); out2 = torch.zeros_like(ref2)
@@ -1200,6 +1184,22 @@ def test_cost_ordered_dispatch_renders_the_same_frames(ctx):
         with pytest.raises(rrt.RRTError) as e:
             rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, tile_order=order.id + 1000))
         assert e.value.status == 4
+        # the sort on geometries past one block-chunk per 1 024 keys (csrc/rrt_tile_sort.h: > 2^20 tiles doubles the chunk) and on
+        # ragged ones: a few march steps per ray are enough to give the tiles costs; the order must be the stable sort
+        for wb, hb in ((8200, 8208), (1000, 700), (8, 8)):
+            big = torch.zeros(hb * wb * 4, dtype=torch.uint8, device="cuda")
+            for _ in range(2):
+                rrt.launch_raymarch(big, wb, hb, 1.0, views[1][0], tex, fx, rrt.RenderParams(spin=0.9, max_steps=6, tile_order=order.id))
+            torch.cuda.synchronize()
+            info = order.info(arrays=True)
+            gx, gy = (wb + 7) // 8, (hb + 7) // 8
+            assert info["n_tiles"] == gx * gy
+            j = np.arange(gy); mid = (gy - 1) >> 1
+            rb = np.where(j & 1, mid + ((j + 1) >> 1), mid - (j >> 1))
+            static = (rb[:, None] * gx + np.arange(gx)[None, :]).reshape(-1)
+            keys = (info["cost"][static] >> 6) & 0xffff
+            assert np.array_equal(info["perm"], static[np.argsort(-keys.astype(np.int64), kind="stable")]), (wb, hb)
+            del big
     finally:
         order.destroy(); nt.destroy()
 

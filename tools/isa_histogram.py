@@ -160,9 +160,9 @@ def main():
     src = listing()
     names = [l.split(":")[0] for l in src if re.match(r"^_ZN12_GLOBAL__N_1\w+:", l)]
     dm = demangled(names)
-    want = sys.argv[1:] or ["raymarch_pixels<true, 0, false, false>", "raymarch_pixels<false, 0, false, false>",
-                            "raymarch_pixels<true, 1, false, false>", "raymarch_pixels<true, 2, false, false>",
-                            "raymarch_pixels<true, 0, false, true>"]
+    want = sys.argv[1:] or ["raymarch_pixels<true, 0, false, 0>", "raymarch_pixels<false, 0, false, 0>",
+                            "raymarch_pixels<true, 1, false, 0>", "raymarch_pixels<true, 2, false, 0>",
+                            "raymarch_pixels<true, 0, false, 2>", "raymarch_pixels<true, 2, false, 2>", "raymarch_pixels<true, 0, false, 1>"]
     for w in want:
         for n in names:
             if w in dm[n]:
