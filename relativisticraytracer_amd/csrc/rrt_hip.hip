@@ -112,7 +112,7 @@ rrt_sky_t sky_register(const SkyObject& s) {
  * The pool is handed out in blocks of kBlockRows rows, and blocks in runs of consecutive blocks whose
  * length doubles (1, 2, 4 ... kMaxRun = 8) every time a wave comes back for more: one atomic per run (a
  * single counter saturates near 90 atomics/us) and only ~log2(n) dependent pointer hops when pass 3
- * walks a heavy wave's samples.  Block layout: kBlockRows x six SoA float[64] planes (p.xyz, vel.xyz in;
+ * walks a heavy wave's samples.  Block layout: kBlockRows x five SoA float[64] planes (p.xyz, vel.x, vel.z in;
  * ex, ey, ez, transmittance out in planes 0-3), then a trailer {lane mask of each row; in the first
  * block of a run: start and length of the wave's next run}.  Unused rows keep a zero mask. */
 /* Round 4: the pool is reused in ROUNDS.  A round = march until the pool is full (waves the pool ran out under are
@@ -142,7 +142,13 @@ struct WaveHdr { unsigned first_block, n_runs, state, flags; };
 constexpr unsigned kMaxRun = RRT_MAX_RUN;
 constexpr unsigned kMaxRunsWalked = 4096;                          /* runs of one wave that pass 3 will walk */
 constexpr unsigned kBlockRows = 8;
-constexpr unsigned kRowData = 6 * 256;
+/* Round 5: a row is FIVE float[64] planes in (p.xyz, vel.x, vel.z), was six.  The only consumer of the sample's velocity is
+ * calculateRedshiftFactor's cos_theta = dot(ray_vel, gas_dir) (geodesics.h:18-19), and gas_dir.y is +0 exactly (0 / mag), so
+ * vel.y only ever enters as vel.y * 0 = +-0 added to vel.x * gas_dir.x: it can change the sign of a zero cos_theta and nothing
+ * else (1 - v * (+-0) = 1) -- unless vel.y is not finite, when the product is NaN; the march poisons vel.x with NaN in that
+ * case, which makes cos_theta the same NaN.  17 % less pool traffic on the way in (profiles/r05_pass_counters_*.txt). */
+constexpr unsigned kRowPlanes = 5;
+constexpr unsigned kRowData = kRowPlanes * 256;
 constexpr unsigned kBlockTrailer = kBlockRows * kRowData;         /* masks[kBlockRows] (u64), then next (u32) */
 constexpr unsigned kBlockBytes = kBlockTrailer + kBlockRows * 8 + 64;
 constexpr unsigned kNoBlock = 0xffffffffu;
@@ -358,9 +364,10 @@ struct FrameArgs {
     const unsigned* tile_perm;
     unsigned* tile_cost;
     int tile_order_id;      /* host side only: rrt_params.tile_order */
-    /* a launch that covers only dispatch rows [grid_row_base, grid_row_base + gridDim.y) of a frame's grid_rows rows of
-     * wave tiles (the three-pass path's chains, round 4); grid_rows == 0: the kernel's own grid is the whole launch */
-    int grid_rows, grid_row_base;
+    /* a launch that covers only dispatch rows grid_row_base + k * grid_row_stride, k < gridDim.y, of a frame's grid_rows rows
+     * of wave tiles (the three-pass path's chains, round 4; stride 2 = every other row, round 5); grid_rows == 0: the kernel's
+     * own grid is the whole launch */
+    int grid_rows, grid_row_base, grid_row_stride;
 };
 
 /* ------------------------------------------------------------------ explicit tile -> shard maps (rrt_tile_map)
@@ -725,7 +732,7 @@ constexpr int kMaxGridY = 65535;               /* HIP's limit for gridDim.y: a l
 /* Workgroups are dispatched in blockIdx order; the rows through the middle of the frame hold the
  * longest rays (shadow edge, disk), so row-blocks are visited from the middle outwards: mid, mid+1,
  * mid-1, ...  Longest-first shortens the tail of a launch; it changes no pixel. */
-__device__ __forceinline__ int dispatch_row(const FrameArgs& a) { return a.grid_row_base + (int)blockIdx.y; }
+__device__ __forceinline__ int dispatch_row(const FrameArgs& a) { return a.grid_row_base + (int)blockIdx.y * a.grid_row_stride; }
 __device__ __forceinline__ int row_block(const FrameArgs& a) {
     const int nb = a.grid_rows ? a.grid_rows : (int)gridDim.y, j = dispatch_row(a), mid = (nb - 1) >> 1;
     return (j & 1) ? mid + ((j + 1) >> 1) : mid - (j >> 1);
@@ -914,8 +921,11 @@ __global__ __launch_bounds__(kWGThreads, RRT_DEFER_WAVES) RRT_DEFER_SGPR_ATTR vo
         }
 
         /* Both density functions return 0 unless the cylindrical radius rc = sqrtf(x*x + 0*0 + z*z) is in
-         * [ISCO, DISK_OUT] (densities.h:21-22, :70-71); only those steps need a sample.  rc comes from
-         * sqrt_rsq, which equals sqrtf bit for bit on [1, 2^64) (self-checked); rc2 < 1 is outside anyway.
+         * [ISCO, DISK_OUT] (densities.h:21-22, :70-71), and behind disk_point()'s first exact early-out, y^2 rc > 135; only
+         * the other steps need a sample.  Round 5: the test here is a cheap SUPERSET of that gate on rc^2 -- no square root:
+         * rc = RN(sqrt(rc2)) in [10, 25] implies rc2 in (99.9999, 625.0002), and RN(RN(y y) rc) <= 135 implies
+         * (y y)^2 rc2 <= 135^2 (1 + 2e-6) -- the few samples it admits beyond the exact gate evaluate to the identity in pass 2
+         * (disk_point() returns false) and are dropped there, so the bytes cannot depend on it.
          * The row is reserved BEFORE the step is taken: if the pool is full the lane stops here with its
          * pre-step state intact, and the next round (or, after the last one, pass 3 in line) resumes it. */
         unsigned long long need_mask = 0ull;
@@ -924,12 +934,8 @@ __global__ __launch_bounds__(kWGThreads, RRT_DEFER_WAVES) RRT_DEFER_SGPR_ATTR vo
         if (!vacuum && __any(in_disk || in_cloud)) {
             if (in_disk || in_cloud) {
                 const float rc2 = rel_p.x * rel_p.x + 0.0f * 0.0f + rel_p.z * rel_p.z;
-                float rc, rci;
-                sqrt_rsq(rc2, rc, rci);
-                /* ... and, inside the gate, unless y^2 rc > 135 -- disk_point()'s first exact early-out, the same
-                 * expression on the same correctly rounded rc: such a sample evaluates to the identity, so it is not
-                 * pooled at all (round 4: a third fewer rows on the bench view, whose rays cross the |y| < 4 zone steeply) */
-                need = rc2 >= 1.0f && !(rc < kIsco || rc > kDiskOut) && !((rel_p.y * rel_p.y) * rc > 135.0f);
+                const float yy = rel_p.y * rel_p.y;
+                need = rc2 >= 99.99f && rc2 <= 625.01f && (yy * yy) * rc2 <= 18227.0f;          /* 135^2 = 18225 */
             }
             need_mask = __ballot(need);
         }
@@ -991,7 +997,8 @@ __global__ __launch_bounds__(kWGThreads, RRT_DEFER_WAVES) RRT_DEFER_SGPR_ATTR vo
 
         if (!vacuum && need) {                                                /* pre-step position, post-step velocity */
             row_f[0] = rel_p.x; row_f[64] = rel_p.y; row_f[128] = rel_p.z;
-            row_f[192] = vel.x; row_f[256] = vel.y; row_f[320] = vel.z;
+            /* vel.y is not stored (kRowPlanes); a non-finite one travels as a NaN in vel.x (vel.y - vel.y is 0 iff finite) */
+            row_f[192] = (vel.y - vel.y == 0.0f) ? vel.x : __builtin_nanf(""); row_f[256] = vel.z;
         }
         if (r > 250.0f && (FMA ? dot_fma(rel_p, vel) : dot(rel_p, vel)) > 0.0f) { ++i; break; }
     }
@@ -1046,27 +1053,38 @@ __global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
     const unsigned n_blk = min(a.ctr->next_block, a.block_capacity);
     const unsigned total = n_blk * kBlockRows;
     const unsigned n_waves = gridDim.x * 4u;
+    /* (Round 5 also tried this loop software-pipelined by hand -- the next row's planes and the mask after it in flight while a
+     * row is evaluated -- and measured nothing, 58.2 against 58.6-59.0 ms on the key-1 frame: the head-of-row round trip is not
+     * what keeps this kernel at 0.62-0.65 of the VALU issue rate; profiles/r05_eval_prefetch_ab.txt.) */
     for (unsigned row = blockIdx.x * 4u + (threadIdx.x >> 6); row < total; row += n_waves) {
         uint8_t* blk = a.sample_blocks + (size_t)(row / kBlockRows) * kBlockBytes;
         const unsigned k = row % kBlockRows;
-        const unsigned long long mask = reinterpret_cast<const unsigned long long*>(blk + kBlockTrailer)[k];
-        if (!((mask >> lane) & 1ull)) continue;
+        unsigned long long* mask_p = reinterpret_cast<unsigned long long*>(blk + kBlockTrailer) + k;
+        const unsigned long long mask = *mask_p;
+        if (mask == 0ull) continue;                                   /* wave-uniform */
+        const bool mine = (mask >> lane) & 1ull;
         float* f = reinterpret_cast<float*>(blk + k * kRowData) + lane;
-        const v3 rel_p = mk(f[0], f[64], f[128]);
-        const v3 vel = mk(f[192], f[256], f[320]);
-        float r2, r, yv;
-        march_radius<ARITH>(rel_p, r2, r, yv);
-        const bool near_bh = r < 18.0f;
-        const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
-        const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
-        const float h = near_bh ? kHNear : (in_disk ? kHDisk : kHVac);
-        float d_disk, d_cloud;
-        media_densities<LUT>(rel_p, a.time, in_disk, in_cloud, a.lut_acc, a.lut_dust, nullptr, d_disk, d_cloud);
-        float ex, ey, ez, s;
-        if (!sample_emission(d_disk, d_cloud, rel_p, r, vel, h, a.spin, ex, ey, ez, s)) {
-            ex = 0.f; ey = 0.f; ez = 0.f; s = 1.0f;       /* identity for accumulate_emission */
+        bool has = false;
+        float ex = 0.f, ey = 0.f, ez = 0.f, s = 1.0f;
+        if (mine) {
+            const v3 rel_p = mk(f[0], f[64], f[128]);
+            const v3 vel = mk(f[192], 0.0f, f[256]);                  /* vel.y: see kRowPlanes */
+            float r2, r, yv;
+            march_radius<ARITH>(rel_p, r2, r, yv);
+            const bool near_bh = r < 18.0f;
+            const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
+            const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
+            const float h = near_bh ? kHNear : (in_disk ? kHDisk : kHVac);
+            float d_disk, d_cloud;
+            media_densities<LUT>(rel_p, a.time, in_disk, in_cloud, a.lut_acc, a.lut_dust, nullptr, d_disk, d_cloud);
+            has = sample_emission(d_disk, d_cloud, rel_p, r, vel, h, a.spin, ex, ey, ez, s);
         }
-        f[0] = ex; f[64] = ey; f[128] = ez; f[192] = s;
+        /* Round 5: a sample raymarcher.cu:71 would not take is the identity of the accumulation -- the single kernel skips it,
+         * and so does pass 3 now: such lanes leave the row's mask instead of storing (0, 0, 0, 1) (the march pools every sample
+         * inside the radial gate and the slab: from inside the disk most of them are real, on the bench view most are not). */
+        const unsigned long long live = __ballot(has);
+        if (has) { f[0] = ex; f[64] = ey; f[128] = ez; f[192] = s; }
+        if (live != mask && lane == (int)(__ffsll((long long)mask) - 1)) *mask_p = live;
     }
 }
 
@@ -1102,8 +1120,9 @@ __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArg
         for (unsigned b = 0; b < run_len; b += kNB) {
             float e[kNB][kBlockRows][4];
             unsigned long long m[kNB][kBlockRows];
-            /* unconditional, address-independent loads (rows a lane does not own are read and ignored):
-             * conditional loads would serialise into one memory round trip per row */
+            /* unconditional, address-independent loads (rows a lane does not own are read and ignored): conditional loads
+             * serialise into one memory round trip per row -- also when the condition is wave-uniform: skipping the rows whose
+             * mask pass 2 has emptied cost this pass 30-150 % (round 5, profiles/r05_pass_counters.txt) for 25 % fewer bytes */
 #pragma unroll
             for (unsigned j = 0; j < kNB; ++j) {
                 const uint8_t* blk = a.sample_blocks + (size_t)(run_start + (b + j < run_len ? b + j : b)) * kBlockBytes;
@@ -1789,7 +1808,7 @@ int fill_args(FrameArgs& a, LaunchOpts& o, void* out, int width, int height, flo
     a.nudge_ulps = prm.nudge_ulps; a.nudge_seed = prm.nudge_seed;
     memset(&a.dbg, 0, sizeof(a.dbg));
     a.tile_perm = nullptr; a.tile_cost = nullptr; a.tile_order_id = prm.tile_order;
-    a.grid_rows = 0; a.grid_row_base = 0;
+    a.grid_rows = 0; a.grid_row_base = 0; a.grid_row_stride = 1;
     if (prm.tile_order != 0) {                      /* whatever path the launch takes: a stale or foreign id is an error */
         const std::shared_ptr<TileOrderObject> to = tile_order_lookup(prm.tile_order);
         if (!to || !on_current_device(to->device)) return RRT_ERR_BAD_HANDLE;
@@ -1877,10 +1896,10 @@ int enqueue_chain_arith(const FrameArgs& a, bool lut, dim3 grid, dim3 block, int
 
 /* one chain = march -> evaluate -> composite (in rounds) over dispatch rows [row0, row1) of the launch, in its own slice
  * of the pool, on its own stream */
-int enqueue_chain(FrameArgs a, int arith, bool lut, dim3 full_grid, int row0, int row1, int rounds, hipStream_t st) {
-    if (row1 <= row0) return RRT_OK;
-    const dim3 block(kWGThreads), grid(full_grid.x, (unsigned)(row1 - row0));
-    a.grid_rows = (int)full_grid.y; a.grid_row_base = row0;
+int enqueue_chain(FrameArgs a, int arith, bool lut, dim3 full_grid, int row0, int row_stride, int n_rows, int rounds, hipStream_t st) {
+    if (n_rows <= 0) return RRT_OK;
+    const dim3 block(kWGThreads), grid(full_grid.x, (unsigned)n_rows);
+    a.grid_rows = (int)full_grid.y; a.grid_row_base = row0; a.grid_row_stride = row_stride;
     if (arith == kArithFast) return enqueue_chain_arith<kArithFast>(a, lut, grid, block, rounds, st);
     if (arith == kArithFmad) return enqueue_chain_arith<kArithFmad>(a, lut, grid, block, rounds, st);
     return enqueue_chain_arith<kArithStrict>(a, lut, grid, block, rounds, st);
@@ -1926,9 +1945,20 @@ int launch_deferred(FrameArgs a, int arith, bool lut, const WorkspaceObject& ws,
     RRT_HIP(hipGetLastError());
     /* the pool's split: by what each chain pooled last time (the heavy half holds most of the media), 65 : 35 without history */
     size_t cap_of[kMaxChains] = {cap, 0};
-    int row_end[kMaxChains] = {(int)grid.y, (int)grid.y};
+    /* which dispatch rows a chain takes: the first and the second half of the static order (the frame's middle and the rest) --
+     * or, when the order is by COST (rrt_tile_order), every other row each: the halves of a cost-sorted order are "all the
+     * expensive tiles" and "all the cheap ones", which made the two chains worse than one (5.15 -> 5.45 ms on an
+     * eighth of the bench frame), while even and odd rows of it carry the same cost */
+    const bool deal_rows = chains == 2 && a.tile_perm != nullptr;
+    int row_first[kMaxChains] = {0, deal_rows ? 1 : (int)grid.y / 2};
+    int row_step = deal_rows ? 2 : 1;
+    int row_count[kMaxChains] = {(int)grid.y, 0};
     if (chains == 2) {
-        double share = 0.65;
+        row_count[0] = deal_rows ? ((int)grid.y + 1) / 2 : (int)grid.y / 2;
+        row_count[1] = (int)grid.y - row_count[0];
+    }
+    if (chains == 2) {
+        double share = deal_rows ? 0.5 : 0.65;
         const volatile DeferCounters* h = ws.h_stats;
         if (h && h[0].rounds_run != 0u && h[1].rounds_run != 0u) {
             const double t0 = (double)h[0].total_blocks, t1 = (double)h[1].total_blocks;
@@ -1937,14 +1967,12 @@ int launch_deferred(FrameArgs a, int arith, bool lut, const WorkspaceObject& ws,
         share = share < 0.3 ? 0.3 : (share > 0.85 ? 0.85 : share);
         cap_of[0] = (size_t)((double)cap * share);
         cap_of[1] = cap - cap_of[0];
-        row_end[0] = (int)grid.y / 2;
     }
     if (chains == 2) {            /* fork: the side stream starts behind the memset, BEFORE anything of chain 0 is in the caller's stream */
         RRT_HIP(hipEventRecord(ws.forked, st));
         RRT_HIP(hipStreamWaitEvent(ws.side, ws.forked, 0));
     }
     size_t block0 = 0;
-    int row0 = 0;
     for (int c = 0; c < chains; ++c) {
         FrameArgs b = a;
         b.ctr = reinterpret_cast<DeferCounters*>(ws.d_base + (size_t)c * kCounterStride);
@@ -1952,7 +1980,7 @@ int launch_deferred(FrameArgs a, int arith, bool lut, const WorkspaceObject& ws,
         b.block_capacity = (unsigned)cap_of[c];
         const int rounds = pool_rounds > 0 ? pool_rounds : auto_pool_rounds(ws.h_stats ? ws.h_stats + c : nullptr, b.block_capacity);
         const hipStream_t cs = c == 1 ? ws.side : st;
-        const int rc = enqueue_chain(b, arith, lut, grid, row0, row_end[c], rounds, cs);
+        const int rc = enqueue_chain(b, arith, lut, grid, row_first[c], row_step, row_count[c], rounds, cs);
         if (rc != RRT_OK) return rc;
         /* what this chain needed, for the next launch's round count and pool split (and rrt_workspace_stats) */
         if (ws.h_stats) RRT_HIP(hipMemcpyAsync(ws.h_stats + c, b.ctr, sizeof(DeferCounters), hipMemcpyDeviceToHost, cs));
@@ -1960,7 +1988,7 @@ int launch_deferred(FrameArgs a, int arith, bool lut, const WorkspaceObject& ws,
             RRT_HIP(hipEventRecord(ws.joined, ws.side));
             RRT_HIP(hipStreamWaitEvent(st, ws.joined, 0));
         }
-        block0 += cap_of[c]; row0 = row_end[c];
+        block0 += cap_of[c];
     }
     if (chains == 1 && ws.h_stats) memset(const_cast<DeferCounters*>(ws.h_stats) + 1, 0, sizeof(DeferCounters));   /* no second chain this time */
     return RRT_OK;
@@ -2804,6 +2832,7 @@ int rrt_probe_tile_costs(int width, int height, int tile_rows, float time, const
     a.use_lens = fx->use_lens_distortion != 0; a.distortion_amount = fx->distortion_amount;
     a.spin = p.spin; a.drag_c = (2.0f * p.spin) * 2.0f; a.max_steps = p.max_steps;
     a.rows = RowMap{height, 0, height, 0, 1, nullptr};
+    a.grid_row_stride = 1;
     const int sy = tile_rows < kProbeStride ? tile_rows : kProbeStride;
     ProbeArgs q;
     const int cells_x = (width + kProbeStride - 1) / kProbeStride, cells_y = (height + sy - 1) / sy;

@@ -10,13 +10,20 @@
  * static launch would have given them, which is the right order where costs tie (sky tiles) -- hipcub's ties came out in
  * tile-index order, top row first.
  *
- * How: LSD radix sort, two passes of 8 bits, each pass = per-block digit histogram -> exclusive scan over (digit, block)
- * -> stable scatter.  64-wide wavefronts rank their lanes with ballots (eight ballots give every lane the mask of the lanes
- * that hold the same digit; popcount below the lane = its rank), four wavefronts of a block split its chunk in order, and
- * LDS holds the block's per-wave digit counters.  Pass 0 reads the costs through the static slot -> tile map and fuses the
- * NEXT pass's block histogram into its scatter (the destination of an element says which block will read it), so a sort is
- * five launches: histogram, scan, scatter(+histogram), scan, scatter.  Everything a pass touches (<= 4 MB at 8K) stays in L2.
- * No spin-waits, no inter-block communication other than kernel boundaries.
+ * How: LSD radix sort, two passes of 8 bits, THREE launches: histogram, scatter, scatter.  The problem is small (0.5 MB of
+ * keys at 4K) and entirely latency-bound, so the design minimises dependent memory round trips and kernel boundaries rather
+ * than maximising parallelism:
+ *   - few fat blocks: 256 threads x 16 keys = 4 096 keys per block (32 blocks at 4K), all 16 keys of a thread loaded in one
+ *     batch and kept in registers for both the counting and the scattering phase of the kernel;
+ *   - no scan kernel: counters live as hist[block][digit]; a scatter block's thread d walks its digit's column once
+ *     (n_blocks coalesced loads, issued together with the key loads), which gives it the digit's total and the count of the
+ *     blocks before its own; an LDS scan of the 256 totals finishes the offsets;
+ *   - pass 0 reads the costs through the static slot -> tile map and builds the NEXT pass's hist[][] with global atomics
+ *     while it scatters (the destination of a key says which block will read it), so pass 1 needs no histogram launch;
+ *   - 64-wide wavefronts rank their lanes with ballots (eight ballots give every lane the mask of the lanes that hold the
+ *     same digit; the popcount below the lane is its rank); the four wavefronts of a block take consecutive quarters of its
+ *     chunk, LDS holds their per-digit write cursors.
+ * No spin-waits, no inter-block communication other than kernel boundaries and those atomics.
  */
 #ifndef RRT_TILE_SORT_H
 #define RRT_TILE_SORT_H
@@ -27,18 +34,19 @@
 namespace rrt_sort {
 
 constexpr unsigned kThreads = 256;            /* four wavefronts per block */
-constexpr unsigned kMaxBlocks = 1024;         /* the scan kernel is one block: bound what it has to scan (256 K counters) */
-constexpr unsigned kScanThreads = 1024;
+constexpr unsigned kItems = 16;               /* keys per thread and batch */
+constexpr unsigned kBatch = kThreads * kItems;   /* 4 096 keys */
+constexpr unsigned kMaxBlocks = 1024;         /* a scatter thread walks a column of n_blocks counters: bound it */
 
-/* keys per block: 1024 (four per thread) unless that would need more than kMaxBlocks blocks */
-inline unsigned chunk_for(size_t n) {
-    size_t c = 1024;
-    while ((n + c - 1) / c > kMaxBlocks) c *= 2;
-    return (unsigned)c;
+/* batches per block: 1 unless n needs more than kMaxBlocks blocks (> 4 M wave tiles) */
+inline unsigned reps_for(size_t n) {
+    size_t r = 1;
+    while ((n + kBatch * r - 1) / (kBatch * r) > kMaxBlocks) r *= 2;
+    return (unsigned)r;
 }
-inline unsigned blocks_for(size_t n) { const unsigned c = chunk_for(n); return (unsigned)((n + c - 1) / c); }
-/* unsigned words of scratch a sort of n keys needs: two (digit, block) counter matrices */
-inline size_t scratch_words(size_t n) { return (size_t)2 * 256 * blocks_for(n); }
+inline unsigned blocks_for(size_t n) { const size_t c = (size_t)kBatch * reps_for(n); return (unsigned)((n + c - 1) / c); }
+/* unsigned words of scratch any sort needs: two hist[block][digit] matrices */
+constexpr size_t kScratchWords = (size_t)2 * 256 * kMaxBlocks;
 
 /* dispatch slot -> wave tile of the static order (rrt_hip.hip: row_block): row blocks mid, mid+1, mid-1 ... */
 __device__ __forceinline__ unsigned static_tile(unsigned slot, unsigned grid_x, unsigned grid_y) {
@@ -57,135 +65,146 @@ struct Pass {
     const unsigned* vals_in;
     unsigned* keys_out;            /* pass 0 only */
     unsigned* vals_out;
-    unsigned* hist;                /* [256][n_blocks] of THIS pass: counts in, exclusive offsets after the scan */
-    unsigned* hist_next;           /* pass 0: the next pass's counters (zeroed by the histogram kernel, filled by the scatter) */
-    unsigned n, chunk, n_blocks, grid_x, grid_y;
+    unsigned* hist;                /* [n_blocks][256] counts of THIS pass */
+    unsigned* hist_next;           /* pass 0: the next pass's counts (zeroed by the histogram kernel, filled by the scatter) */
+    unsigned n, reps, n_blocks, grid_x, grid_y;
     int shift, shift_next;
 };
 
+/* element i of the pass's input; an index past the end reads as (key 0, tile 0) and is never written anywhere */
 template <int PASS>
 __device__ __forceinline__ void load_item(const Pass& p, unsigned i, unsigned& key, unsigned& val) {
-    if (PASS == 0) { val = static_tile(i, p.grid_x, p.grid_y); key = p.cost[val]; }
-    else { key = p.keys_in[i]; val = p.vals_in[i]; }
+    key = 0u; val = 0u;
+    if (i < p.n) {
+        if (PASS == 0) { val = static_tile(i, p.grid_x, p.grid_y); key = p.cost[val]; }
+        else { key = p.keys_in[i]; val = p.vals_in[i]; }
+    }
 }
 
-/* pass 0 only: per-block digit counts of the block's chunk -> hist[d][block]; zero the next pass's column */
+/* pass 0 only: hist[block][d] = digit counts of the block's chunk; the next pass's row is zeroed */
 __global__ __launch_bounds__(kThreads) void histogram0(Pass p) {
     __shared__ unsigned h[256];
     h[threadIdx.x] = 0u;
     __syncthreads();
-    const unsigned base = blockIdx.x * p.chunk;
-    for (unsigned k = threadIdx.x; k < p.chunk; k += kThreads) {
-        const unsigned i = base + k;
-        if (i < p.n) {
-            unsigned key, val;
-            load_item<0>(p, i, key, val);
-            atomicAdd(&h[digit_of(key, p.shift)], 1u);
-        }
-    }
-    __syncthreads();
-    p.hist[threadIdx.x * p.n_blocks + blockIdx.x] = h[threadIdx.x];
-    p.hist_next[threadIdx.x * p.n_blocks + blockIdx.x] = 0u;
-}
-
-/* exclusive scan of m counters in place, one block */
-__global__ __launch_bounds__(kScanThreads) void scan_counters(unsigned* c, unsigned m) {
-    __shared__ unsigned wave_sum[kScanThreads / 64];
-    const unsigned per = (m + kScanThreads - 1) / kScanThreads;
-    const unsigned lo = threadIdx.x * per, hi = lo + per < m ? lo + per : m;
-    unsigned s = 0u;
-    for (unsigned i = lo; i < hi; ++i) s += c[i];
-    /* inclusive scan inside the wavefront */
-    unsigned incl = s;
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned base = blockIdx.x * kBatch * p.reps;
+    for (unsigned r = 0; r < p.reps; ++r) {
+        unsigned key[kItems], val[kItems];
 #pragma unroll
-    for (unsigned o = 1; o < 64; o <<= 1) {
-        const unsigned up = (unsigned)__shfl_up((int)incl, o);
-        if (lane >= o) incl += up;
+        for (unsigned k = 0; k < kItems; ++k) load_item<0>(p, base + r * kBatch + k * kThreads + threadIdx.x, key[k], val[k]);
+#pragma unroll
+        for (unsigned k = 0; k < kItems; ++k)
+            if (base + r * kBatch + k * kThreads + threadIdx.x < p.n) atomicAdd(&h[digit_of(key[k], p.shift)], 1u);
     }
-    if (lane == 63u) wave_sum[wave] = incl;
     __syncthreads();
-    unsigned before = 0u;
-    for (unsigned w = 0; w < wave; ++w) before += wave_sum[w];
-    unsigned run = before + incl - s;
-    for (unsigned i = lo; i < hi; ++i) { const unsigned v = c[i]; c[i] = run; run += v; }
+    p.hist[blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];
+    p.hist_next[blockIdx.x * 256u + threadIdx.x] = 0u;
 }
 
-/* stable scatter of the block's chunk to the offsets of the scanned histogram.  The four wavefronts take consecutive
- * quarters of the chunk; each counts its digits (LDS), the counters become the waves' write cursors, then every wavefront
- * walks its quarter 64 keys at a time: a lane's place = its wave's cursor of that digit + the number of lower lanes that
- * hold the same digit. */
+/* Stable scatter of the block's chunk.  Wavefront w owns the w-th quarter of the chunk (consecutive keys), 64 keys per
+ * step in order; a key's place = (keys with a smaller digit anywhere) + (same digit in earlier blocks) + (same digit in
+ * earlier wavefronts of this block) + (same digit earlier in this wavefront's quarter). */
 template <int PASS>
 __global__ __launch_bounds__(kThreads) void scatter(Pass p) {
     __shared__ unsigned cur[4][256];
+    __shared__ unsigned wave_tot[4];
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (unsigned k = threadIdx.x; k < 4u * 256u; k += kThreads) (&cur[0][0])[k] = 0u;
-    __syncthreads();
-    const unsigned quarter = p.chunk / 4u;
-    const unsigned w_base = blockIdx.x * p.chunk + wave * quarter;
-    for (unsigned k = lane; k < quarter; k += 64u) {
-        const unsigned i = w_base + k;
-        if (i < p.n) {
-            unsigned key, val;
-            load_item<PASS>(p, i, key, val);
-            atomicAdd(&cur[wave][digit_of(key, p.shift)], 1u);
+    const unsigned quarter = kItems * 64u * p.reps;                     /* keys per wavefront */
+    const unsigned w_base = blockIdx.x * kBatch * p.reps + wave * quarter;
+    /* the keys of the first batch (the only one unless the frame has > 4 M wave tiles): loads in flight ... */
+    unsigned key[kItems], val[kItems];
+#pragma unroll
+    for (unsigned k = 0; k < kItems; ++k) load_item<PASS>(p, w_base + k * 64u + lane, key[k], val[k]);
+    /* ... together with digit d's column of the block histograms: the digit's total and what the earlier blocks hold */
+    unsigned total = 0u, before = 0u;
+    {
+        const unsigned d = threadIdx.x;
+        for (unsigned b0 = 0; b0 < p.n_blocks; b0 += 8u) {
+            unsigned v[8];
+#pragma unroll
+            for (unsigned j = 0; j < 8u; ++j) v[j] = b0 + j < p.n_blocks ? p.hist[(b0 + j) * 256u + d] : 0u;
+#pragma unroll
+            for (unsigned j = 0; j < 8u; ++j) { total += v[j]; before += b0 + j < blockIdx.x ? v[j] : 0u; }
         }
     }
+    for (unsigned k = threadIdx.x; k < 4u * 256u; k += kThreads) (&cur[0][0])[k] = 0u;
     __syncthreads();
-    {   /* thread d: the four waves' cursors of digit d */
+    /* per-wave digit counts of this block's chunk */
+    for (unsigned r = 0; r < p.reps; ++r) {
+        if (r > 0) {
+#pragma unroll
+            for (unsigned k = 0; k < kItems; ++k) load_item<PASS>(p, w_base + r * kItems * 64u + k * 64u + lane, key[k], val[k]);
+        }
+#pragma unroll
+        for (unsigned k = 0; k < kItems; ++k)
+            if (w_base + r * kItems * 64u + k * 64u + lane < p.n) atomicAdd(&cur[wave][digit_of(key[k], p.shift)], 1u);
+    }
+    /* exclusive scan of the 256 digit totals (thread d holds total[d]) */
+    unsigned incl = total;
+#pragma unroll
+    for (unsigned o = 1; o < 64u; o <<= 1) {
+        const unsigned up = (unsigned)__shfl_up((int)incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63u) wave_tot[wave] = incl;
+    __syncthreads();
+    {
+        unsigned smaller = incl - total;
+        for (unsigned w = 0; w < wave; ++w) smaller += wave_tot[w];
         const unsigned d = threadIdx.x;
-        unsigned at = p.hist[d * p.n_blocks + blockIdx.x];
+        unsigned at = smaller + before;                                  /* where this block's keys of digit d start */
 #pragma unroll
         for (unsigned w = 0; w < 4u; ++w) { const unsigned c = cur[w][d]; cur[w][d] = at; at += c; }
     }
     __syncthreads();
-    for (unsigned k0 = 0; k0 < quarter; k0 += 64u) {           /* wave-uniform trip count */
-        const unsigned i = w_base + k0 + lane;
-        const bool valid = i < p.n;
-        unsigned key = 0u, val = 0u;
-        if (valid) load_item<PASS>(p, i, key, val);
-        const unsigned d = digit_of(key, p.shift);
-        unsigned long long peers = __ballot(valid);
+    for (unsigned r = 0; r < p.reps; ++r) {
+        if (p.reps > 1) {                                                /* more than one batch: reload (the first one too) */
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const unsigned long long has = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? has : ~has;
+            for (unsigned k = 0; k < kItems; ++k) load_item<PASS>(p, w_base + r * kItems * 64u + k * 64u + lane, key[k], val[k]);
         }
-        const unsigned long long below = peers & ((1ull << lane) - 1ull);
-        if (valid) {
-            const unsigned pos = cur[wave][d] + (unsigned)__popcll(below);
-            if (PASS == 0) {
-                p.keys_out[pos] = key;
-                p.vals_out[pos] = val;
-                atomicAdd(&p.hist_next[digit_of(key, p.shift_next) * p.n_blocks + pos / p.chunk], 1u);
-            } else {
-                p.vals_out[pos] = val;
+#pragma unroll
+        for (unsigned k = 0; k < kItems; ++k) {
+            const bool valid = w_base + r * kItems * 64u + k * 64u + lane < p.n;
+            const unsigned d = digit_of(key[k], p.shift);
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const unsigned long long has = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? has : ~has;
             }
+            const unsigned long long below = peers & ((1ull << lane) - 1ull);
+            if (valid) {
+                const unsigned pos = cur[wave][d] + (unsigned)__popcll(below);
+                if (PASS == 0) {
+                    p.keys_out[pos] = key[k];
+                    p.vals_out[pos] = val[k];
+                    atomicAdd(&p.hist_next[(pos / (kBatch * p.reps)) * 256u + digit_of(key[k], p.shift_next)], 1u);
+                } else {
+                    p.vals_out[pos] = val[k];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                    /* every lane has read its cursor before the leaders move them */
+            if (valid && below == 0ull) cur[wave][d] += (unsigned)__popcll(peers);
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();                        /* every lane has read its cursor before the leaders move them */
-        if (valid && below == 0ull) cur[wave][d] += (unsigned)__popcll(peers);
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
 /* Enqueue the sort on `st`: perm_out[slot] = wave tile, longest first.  keys_tmp / vals_tmp: n words each; scratch:
- * scratch_words(n) words.  lo_bit: the lowest of the 16 key bits.  Returns the first HIP launch error. */
+ * kScratchWords words.  lo_bit: the lowest of the 16 key bits.  Returns the first HIP launch error. */
 inline hipError_t enqueue(const unsigned* d_cost, unsigned* d_keys_tmp, unsigned* d_vals_tmp, unsigned* d_scratch, unsigned* d_perm_out,
                           size_t n, unsigned grid_x, unsigned grid_y, int lo_bit, hipStream_t st) {
     if (n == 0) return hipSuccess;
     Pass p{};
-    p.n = (unsigned)n; p.chunk = chunk_for(n); p.n_blocks = blocks_for(n); p.grid_x = grid_x; p.grid_y = grid_y;
+    p.n = (unsigned)n; p.reps = reps_for(n); p.n_blocks = blocks_for(n); p.grid_x = grid_x; p.grid_y = grid_y;
     unsigned* hist0 = d_scratch;
-    unsigned* hist1 = d_scratch + (size_t)256 * p.n_blocks;
+    unsigned* hist1 = d_scratch + (size_t)256 * kMaxBlocks;
     p.cost = d_cost; p.keys_out = d_keys_tmp; p.vals_out = d_vals_tmp;
     p.hist = hist0; p.hist_next = hist1; p.shift = lo_bit; p.shift_next = lo_bit + 8;
     hipLaunchKernelGGL(histogram0, dim3(p.n_blocks), dim3(kThreads), 0, st, p);
-    hipLaunchKernelGGL(scan_counters, dim3(1), dim3(kScanThreads), 0, st, hist0, 256u * p.n_blocks);
     hipLaunchKernelGGL(scatter<0>, dim3(p.n_blocks), dim3(kThreads), 0, st, p);
     Pass q = p;
     q.cost = nullptr; q.keys_in = d_keys_tmp; q.vals_in = d_vals_tmp; q.keys_out = nullptr; q.vals_out = d_perm_out;
     q.hist = hist1; q.hist_next = nullptr; q.shift = lo_bit + 8; q.shift_next = 0;
-    hipLaunchKernelGGL(scan_counters, dim3(1), dim3(kScanThreads), 0, st, hist1, 256u * p.n_blocks);
     hipLaunchKernelGGL(scatter<1>, dim3(p.n_blocks), dim3(kThreads), 0, st, q);
     return hipGetLastError();
 }

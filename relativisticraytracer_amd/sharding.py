@@ -113,8 +113,13 @@ class Watchdog:
         self.armed = False
 
     def arm(self, seconds, what):
+        """(Re-)start the countdown.  The previous one is ALWAYS cancelled first, so arm(0) / arm(None) means "no limit from
+        here on" and not "keep counting down the limit of the phase before" (headless.py re-arms every frame, and
+        with --frame-timeout 0 frame 1's bring-up allowance went on to kill a healthy run)."""
         import faulthandler
         import sys
+        faulthandler.cancel_dump_traceback_later()
+        self.armed = False
         if seconds and seconds > 0:
             if self.verbose():
                 print(f"[{self.label}] watchdog: {what} (limit {seconds:.0f} s)", file=sys.stderr, flush=True)

@@ -89,6 +89,20 @@ def test_watchdog_ends_a_stuck_run_with_tracebacks():
     assert r.returncode != 0 and "Timeout (0:00:01)" in r.stderr and "stuck" in r.stderr
 
 
+def test_watchdog_arm_zero_means_no_limit():
+    """arm(0) used to do nothing AND leave the previous countdown running -- headless.py re-arms every frame, so with
+    `--frame-timeout 0` the bring-up allowance armed before frame 1 killed a healthy run.  arm() now always cancels first."""
+    import subprocess
+    code = ("import time, sys; sys.path.insert(0, %r)\n"
+            "from relativisticraytracer_amd.sharding import Watchdog\n"
+            "d = Watchdog('t'); d.arm(0.3, 'bring-up + frame 1')\n"
+            "for k in range(4):\n    d.arm(0, 'frame, no limit'); time.sleep(0.2)\n"
+            "d.arm(None, 'no limit either'); time.sleep(0.2)\n"
+            "print('alive')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0 and "alive" in r.stdout and "Timeout" not in r.stderr, (r.returncode, r.stderr[-300:])
+
+
 def test_single_node_environment_only_fills_what_is_unset():
     env = {"MASTER_ADDR": "127.0.0.1"}
     sh.single_node_environment(env)
