@@ -43,7 +43,7 @@ def source_hash():
     it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("rrt_hip.hip", "rrt_device.h", "rrt_math.h", "rrt_tile_sort.h"):
+    for f in ("rrt_hip.hip", "rrt_kernels.h", "rrt_device.h", "rrt_math.h", "rrt_tile_sort.h"):
         h.update(open(os.path.join(ROOT, "relativisticraytracer_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -2,12 +2,18 @@
 
 There is deliberately no CPU fallback: if the HIP library is missing or a
 launch fails, the call raises.
+
+load()       the product library, what the package, bench.py and smoke() use;
+load_test()  librrt_hip_test.so -- the same sources built with -DRRT_TEST_HOOKS: everything above plus the entry points of
+             include/rrt_test.h (rrt_unit_*, rrt_selfcheck_*, rrt_debug_fake_device).  A separate library with its own
+             handle registries: objects created through one are unknown to the other.  Tests only.
 """
 import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RRT_LIB_OVERRIDE") or os.path.join(PKG, "lib", "librrt_hip.so")   # override: dev A/B builds only
+TEST_LIB_PATH = os.path.join(PKG, "lib", "librrt_hip_test.so")
 
 RRT_OK = 0
 
@@ -87,7 +93,6 @@ SYMBOLS = [
     ("rrt_noise_table_window", _i, [_i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_i), C.POINTER(_i)]),
     ("rrt_noise_table_plan_window", _i, [_f, _f, _i, C.POINTER(C.c_size_t), C.POINTER(_i * 12)]),
     ("rrt_noise_table_fit_window", _i, [_f, _f, C.c_size_t, C.POINTER(_f), C.POINTER(_i), C.POINTER(C.c_size_t)]),
-    ("rrt_debug_fake_device", _i, [_i]),
     ("rrt_set_launch_defaults", _i, [_prm]),
     ("rrt_get_launch_defaults_sized", _i, [_vp, C.c_uint32]),
     ("rrt_launch_raymarch_compat", _i, [_vp, _i, _i, _f, C.POINTER(C.c_float * 12), _ull, _vp]),
@@ -101,6 +106,19 @@ SYMBOLS = [
     ("rrt_assemble_all_tiles", _i, [_vp, _vp, C.c_size_t, _i, _i, _i, _i, _vp]),
     ("rrt_launch_raymarch_ex", _i, [_vp, _i, _i, _f, _cam, _ull, _fx, _prm,
                                     C.POINTER(rrt_debug_outputs), _vp]),
+    ("rrt_camera_from_angles", _i, [C.POINTER(C.c_float * 3), _f, _f, _cam]),
+    ("rrt_catmull_rom", _i, [C.POINTER(C.c_float * 3)] * 4 + [_f, C.POINTER(C.c_float * 3)]),
+    ("rrt_lerp_angle", _i, [_f, _f, _f, C.POINTER(_f)]),
+    ("rrt_path_count", _i, []),
+    ("rrt_path_info", _i, [_i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_f)]),
+    ("rrt_path_keyframes", _i, [_i, _vp, _i]),
+    ("rrt_path_camera_at", _i, [_i, _f, _cam]),
+    ("rrt_recording_clock", _i, [_i, _i, C.POINTER(_f), C.POINTER(_f)]),
+]
+
+# include/rrt_test.h: librrt_hip_test.so only
+TEST_SYMBOLS = [
+    ("rrt_debug_fake_device", _i, [_i]),
     ("rrt_unit_geodesic_acc", _i, [_i, _vp, _vp, _f, _vp, _vp]),
     ("rrt_unit_rk4", _i, [_i, _vp, _vp, _vp, _f, _vp]),
     ("rrt_unit_rk4_lean", _i, [_i, _vp, _vp, _vp, _f, _i, _f, _vp, _vp]),
@@ -126,17 +144,58 @@ SYMBOLS = [
     ("rrt_selfcheck_div_tame", _i, [_ull, C.c_uint32, _vp, _vp]),
     ("rrt_selfcheck_div_const", _i, [C.c_uint32, C.c_uint32, _vp, _vp]),
     ("rrt_selfcheck_sqrt_seeded", _i, [C.c_uint32, C.c_uint32, _vp, _vp]),
-    ("rrt_camera_from_angles", _i, [C.POINTER(C.c_float * 3), _f, _f, _cam]),
-    ("rrt_catmull_rom", _i, [C.POINTER(C.c_float * 3)] * 4 + [_f, C.POINTER(C.c_float * 3)]),
-    ("rrt_lerp_angle", _i, [_f, _f, _f, C.POINTER(_f)]),
-    ("rrt_path_count", _i, []),
-    ("rrt_path_info", _i, [_i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_f)]),
-    ("rrt_path_keyframes", _i, [_i, _vp, _i]),
-    ("rrt_path_camera_at", _i, [_i, _f, _cam]),
-    ("rrt_recording_clock", _i, [_i, _i, C.POINTER(_f), C.POINTER(_f)]),
 ]
 
 _lib = None
+_test_lib = None
+
+
+def _bind(lib, symbols, tolerate_missing=False):
+    for name, res, args in symbols:
+        try:
+            fn = getattr(lib, name)      # AttributeError if the export is missing
+        except AttributeError:
+            if tolerate_missing:
+                continue
+            raise
+        fn.restype = res
+        fn.argtypes = args
+
+
+def load_test():
+    """Load librrt_hip_test.so (product + test hooks, include/rrt_test.h).  Tests and dev tools only."""
+    global _test_lib
+    if _test_lib is not None:
+        return _test_lib
+    if not os.path.exists(TEST_LIB_PATH):
+        raise RRTError(-1, "librrt_hip_test.so is missing",
+                       f"expected {TEST_LIB_PATH}; run `python -m relativisticraytracer_amd.build`")
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(TEST_LIB_PATH)
+    _bind(lib, SYMBOLS)
+    _bind(lib, TEST_SYMBOLS)
+    _test_lib = lib
+    return lib
+
+
+class using_test_library:
+    """Tests only: inside `with _lib.using_test_library() as lib:` the whole package talks to librrt_hip_test.so instead of
+    the product library (load() returns it), so that the Python wrappers and the test hooks share one set of handle
+    registries.  Objects created inside must be destroyed inside."""
+
+    def __enter__(self):
+        global _lib
+        self.prev = _lib
+        _lib = load_test()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
 
 
 def load():
@@ -152,16 +211,8 @@ def load():
     except Exception:
         pass
     lib = C.CDLL(LIB_PATH)
-    dev_override = "RRT_LIB_OVERRIDE" in os.environ     # A/B timing of an older build (tools/ab_*.py): tolerate
-    for name, res, args in SYMBOLS:                      # exports it does not have yet; the shipped library must have all
-        try:
-            fn = getattr(lib, name)      # AttributeError if the export is missing
-        except AttributeError:
-            if dev_override:
-                continue
-            raise
-        fn.restype = res
-        fn.argtypes = args
+    # A/B timing of an older build (tools/ab_*.py): tolerate exports it does not have yet; the shipped library must have all
+    _bind(lib, SYMBOLS, tolerate_missing="RRT_LIB_OVERRIDE" in os.environ)
     _lib = lib
     return lib
 

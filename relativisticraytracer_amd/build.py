@@ -15,10 +15,13 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "librrt_hip.so")
+TEST_LIB = os.path.join(LIBDIR, "librrt_hip_test.so")   # the same sources + -DRRT_TEST_HOOKS: rrt_unit_*, rrt_selfcheck_*, rrt_debug_fake_device
 SOURCES = [os.path.join(CSRC, "rrt_hip.hip")]
 COMPAT_SRC = os.path.join(CSRC, "rrt_compat.cpp")     # launch_raymarch under the reference's mangled name (host only, g++)
-HEADERS = [os.path.join(CSRC, "rrt_device.h"), os.path.join(CSRC, "rrt_math.h"), os.path.join(CSRC, "rrt_tile_sort.h"), COMPAT_SRC,
-           os.path.join(PKG, "..", "include", "rrt.h"), os.path.join(PKG, "..", "include", "raymarcher.h")]
+CAMERA_SRC = os.path.join(CSRC, "rrt_camera.cpp")     # camera basis / path playback (host only, g++)
+HEADERS = [os.path.join(CSRC, f) for f in ("rrt_device.h", "rrt_math.h", "rrt_tile_sort.h", "rrt_kernels.h", "rrt_test_hooks.h")] + [
+    COMPAT_SRC, CAMERA_SRC, os.path.join(PKG, "..", "include", "rrt.h"), os.path.join(PKG, "..", "include", "rrt_test.h"),
+    os.path.join(PKG, "..", "include", "raymarcher.h")]
 
 # -ffp-contract=off: the kernels' arithmetic contract (csrc/rrt_device.h).
 # -fno-slp-vectorize: the SLP vectoriser packs the 3-vector math into v_pk_*_f32 plus a pile of
@@ -43,28 +46,52 @@ def hipcc_path():
 
 
 def is_stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(TEST_LIB):
         return True
-    t = os.path.getmtime(LIB)
+    t = min(os.path.getmtime(LIB), os.path.getmtime(TEST_LIB))
     return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS + [os.path.abspath(__file__)])
 
 
+def host_objects(outdir):
+    """the two plain-C++ translation units (g++): the reference-mangled launch_raymarch and the camera code"""
+    objs = []
+    for src in (COMPAT_SRC, CAMERA_SRC):
+        obj = os.path.join(outdir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-c", src, "-o", obj], check=True)
+        objs.append(obj)
+    return objs
+
+
 def build_lib(force=False, extra_flags=(), verbose=False):
+    """librrt_hip.so (the product) and librrt_hip_test.so (+ test hooks), from the same sources; the two hipcc compiles run
+    side by side."""
     if not force and not is_stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    compat_obj = os.path.join(LIBDIR, "rrt_compat.o")
-    subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-c", COMPAT_SRC, "-o", compat_obj], check=True)
-    # two steps: with a .hip input hipcc compiles every input as HIP source, objects included
-    hip_obj = os.path.join(LIBDIR, "rrt_hip.o")
-    cmd = [hipcc_path()] + [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + ["-c"] + SOURCES + ["-o", hip_obj]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=LIBDIR)
-    link = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", hip_obj, compat_obj, "-o", LIB]
-    if verbose:
-        print(" ".join(link), flush=True)
-    subprocess.run(link, check=True, cwd=LIBDIR)
+    host_objs = host_objects(LIBDIR)
+    # two steps per library: with a .hip input hipcc compiles every input as HIP source, objects included
+    base = [hipcc_path()] + [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
+    jobs = []
+    for obj, defs in ((os.path.join(LIBDIR, "rrt_hip.o"), []), (os.path.join(LIBDIR, "rrt_hip_test.o"), ["-DRRT_TEST_HOOKS"])):
+        cmd = base + defs + ["-c"] + SOURCES + ["-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        if "-save-temps" in extra_flags:       # temporaries of the two compiles would collide: product only, one at a time
+            if defs:
+                continue
+            subprocess.run(cmd, check=True, cwd=LIBDIR)
+        else:
+            jobs.append((cmd, subprocess.Popen(cmd, cwd=LIBDIR)))
+    for cmd, pr in jobs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    for lib, obj in ((LIB, os.path.join(LIBDIR, "rrt_hip.o")), (TEST_LIB, os.path.join(LIBDIR, "rrt_hip_test.o"))):
+        if not os.path.exists(obj) or ("-save-temps" in extra_flags and lib == TEST_LIB):
+            continue
+        link = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", obj] + host_objs + ["-o", lib]
+        if verbose:
+            print(" ".join(link), flush=True)
+        subprocess.run(link, check=True, cwd=LIBDIR)
     return LIB
 
 
@@ -72,9 +99,7 @@ def build_variant(name, extra_flags=()):
     """dev builds for A/B timing: lib/variants/<name>.so with extra hipcc flags (tools/ab_views.py)."""
     vdir = os.path.join(LIBDIR, "variants")
     os.makedirs(vdir, exist_ok=True)
-    compat_obj = os.path.join(LIBDIR, "rrt_compat.o")
-    if not os.path.exists(compat_obj):
-        subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-c", COMPAT_SRC, "-o", compat_obj], check=True)
+    host_objs = host_objects(vdir)
     obj = os.path.join(vdir, name + ".o")
     base = [f for f in HIPCC_FLAGS if f != "-shared"]
     for d in [f[len("--drop="):] for f in extra_flags if f.startswith("--drop=")]:      # --drop=<flag>: build WITHOUT a shipped flag
@@ -86,9 +111,10 @@ def build_variant(name, extra_flags=()):
     extra_flags = [f for f in extra_flags if not f.startswith("--drop=")]
     subprocess.run([hipcc_path()] + base + list(extra_flags) + ["-c"] + SOURCES + ["-o", obj], check=True, cwd=vdir)
     out = os.path.join(vdir, name + ".so")
-    subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", obj, compat_obj, "-o", out],
+    subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", obj] + host_objs + ["-o", out],
                    check=True, cwd=vdir)
-    os.remove(obj)
+    for o in [obj] + host_objs:
+        os.remove(o)
     return out
 
 

@@ -13,8 +13,10 @@
  * How: LSD radix sort, two passes of 8 bits, THREE launches: histogram, scatter, scatter.  The problem is small (0.5 MB of
  * keys at 4K) and entirely latency-bound, so the design minimises dependent memory round trips and kernel boundaries rather
  * than maximising parallelism:
- *   - few fat blocks: 256 threads x 16 keys = 4 096 keys per block (32 blocks at 4K), all 16 keys of a thread loaded in one
- *     batch and kept in registers for both the counting and the scattering phase of the kernel;
+ *   - few fat blocks: 256 threads x 8 keys = 2 048 keys per block (64 blocks at 4K), all keys of a thread loaded in one
+ *     batch and kept in registers for both the counting and the scattering phase of the kernel (a lone wavefront retires an
+ *     instruction every ~10 clocks, so the instruction count per wave is the time: 16 keys per thread took 36 us per scatter,
+ *     1 024-key blocks with a scan kernel in between 46 us; profiles/r05_tile_sort_timing.txt);
  *   - no scan kernel: counters live as hist[block][digit]; a scatter block's thread d walks its digit's column once
  *     (n_blocks coalesced loads, issued together with the key loads), which gives it the digit's total and the count of the
  *     blocks before its own; an LDS scan of the 256 totals finishes the offsets;
@@ -32,13 +34,14 @@
 #include <stdint.h>
 
 namespace rrt_sort {
+namespace {                                   /* internal linkage: the library exports nothing of this */
 
 constexpr unsigned kThreads = 256;            /* four wavefronts per block */
-constexpr unsigned kItems = 16;               /* keys per thread and batch */
-constexpr unsigned kBatch = kThreads * kItems;   /* 4 096 keys */
+constexpr unsigned kItems = 8;                /* keys per thread and batch */
+constexpr unsigned kBatch = kThreads * kItems;   /* 2 048 keys */
 constexpr unsigned kMaxBlocks = 1024;         /* a scatter thread walks a column of n_blocks counters: bound it */
 
-/* batches per block: 1 unless n needs more than kMaxBlocks blocks (> 4 M wave tiles) */
+/* batches per block: 1 unless n needs more than kMaxBlocks blocks (> 2 M wave tiles) */
 inline unsigned reps_for(size_t n) {
     size_t r = 1;
     while ((n + kBatch * r - 1) / (kBatch * r) > kMaxBlocks) r *= 2;
@@ -48,9 +51,11 @@ inline unsigned blocks_for(size_t n) { const size_t c = (size_t)kBatch * reps_fo
 /* unsigned words of scratch any sort needs: two hist[block][digit] matrices */
 constexpr size_t kScratchWords = (size_t)2 * 256 * kMaxBlocks;
 
-/* dispatch slot -> wave tile of the static order (rrt_hip.hip: row_block): row blocks mid, mid+1, mid-1 ... */
-__device__ __forceinline__ unsigned static_tile(unsigned slot, unsigned grid_x, unsigned grid_y) {
-    const unsigned j = slot / grid_x, col = slot - j * grid_x;
+/* dispatch slot -> wave tile of the static order (rrt_kernels.h: row_block): row blocks mid, mid+1, mid-1 ...
+ * slot / grid_x by multiplication: with inv_gx = ceil(2^48 / grid_x) the quotient is exact for slot < 2^30, grid_x < 2^18 (the error
+ * term slot / 2^48 < 2^-18 < 1 / grid_x) and the product fits 64 bits for quotients < 2^16 (gridDim.y <= 65 535) */
+__device__ __forceinline__ unsigned static_tile(unsigned slot, unsigned grid_x, unsigned grid_y, unsigned long long inv_gx) {
+    const unsigned j = (unsigned)(((unsigned long long)slot * inv_gx) >> 48), col = slot - j * grid_x;
     const int mid = ((int)grid_y - 1) >> 1;
     const int rb = (j & 1u) ? mid + (int)((j + 1u) >> 1) : mid - (int)(j >> 1);
     return (unsigned)rb * grid_x + col;
@@ -68,6 +73,7 @@ struct Pass {
     unsigned* hist;                /* [n_blocks][256] counts of THIS pass */
     unsigned* hist_next;           /* pass 0: the next pass's counts (zeroed by the histogram kernel, filled by the scatter) */
     unsigned n, reps, n_blocks, grid_x, grid_y;
+    unsigned long long inv_gx;     /* ceil(2^48 / grid_x) */
     int shift, shift_next;
 };
 
@@ -76,7 +82,7 @@ template <int PASS>
 __device__ __forceinline__ void load_item(const Pass& p, unsigned i, unsigned& key, unsigned& val) {
     key = 0u; val = 0u;
     if (i < p.n) {
-        if (PASS == 0) { val = static_tile(i, p.grid_x, p.grid_y); key = p.cost[val]; }
+        if (PASS == 0) { val = static_tile(i, p.grid_x, p.grid_y, p.inv_gx); key = p.cost[val]; }
         else { key = p.keys_in[i]; val = p.vals_in[i]; }
     }
 }
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(kThreads) void scatter(Pass p) {
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned quarter = kItems * 64u * p.reps;                     /* keys per wavefront */
     const unsigned w_base = blockIdx.x * kBatch * p.reps + wave * quarter;
-    /* the keys of the first batch (the only one unless the frame has > 4 M wave tiles): loads in flight ... */
+    /* the keys of the first batch (the only one unless the frame has > 2 M wave tiles): loads in flight ... */
     unsigned key[kItems], val[kItems];
 #pragma unroll
     for (unsigned k = 0; k < kItems; ++k) load_item<PASS>(p, w_base + k * 64u + lane, key[k], val[k]);
@@ -196,6 +202,7 @@ inline hipError_t enqueue(const unsigned* d_cost, unsigned* d_keys_tmp, unsigned
     if (n == 0) return hipSuccess;
     Pass p{};
     p.n = (unsigned)n; p.reps = reps_for(n); p.n_blocks = blocks_for(n); p.grid_x = grid_x; p.grid_y = grid_y;
+    p.inv_gx = ((1ull << 48) + grid_x - 1) / grid_x;
     unsigned* hist0 = d_scratch;
     unsigned* hist1 = d_scratch + (size_t)256 * kMaxBlocks;
     p.cost = d_cost; p.keys_out = d_keys_tmp; p.vals_out = d_vals_tmp;
@@ -209,5 +216,6 @@ inline hipError_t enqueue(const unsigned* d_cost, unsigned* d_keys_tmp, unsigned
     return hipGetLastError();
 }
 
+}  // namespace
 }  // namespace rrt_sort
 #endif

@@ -15,11 +15,51 @@ def host(t):
     return t.cpu().numpy()
 
 
+class HookSky:
+    """A sky in librrt_hip_TEST.so's registry (the test library is a separate library: the package's SkyTexture lives in the
+    product library's and is unknown to rrt_unit_sky_sample)."""
+
+    def __init__(self, rgba8):
+        from relativisticraytracer_amd import _lib
+        arr = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        h = C.c_ulonglong(0)
+        _lib.check(_lib.load_test().rrt_sky_create(arr.ctypes.data_as(C.c_void_p), arr.shape[1], arr.shape[0], C.byref(h)), "rrt_sky_create")
+        self.handle = h.value
+
+    def destroy(self):
+        from relativisticraytracer_amd import _lib
+        if self.handle:
+            _lib.load_test().rrt_sky_destroy(self.handle)
+            self.handle = 0
+
+
+class HookNoiseTable:
+    """A noise table in the test library's registry (see HookSky)."""
+
+    def __init__(self, t_max):
+        from relativisticraytracer_amd import _lib
+        i = C.c_int(0)
+        _lib.check(_lib.load_test().rrt_noise_table_create(float(t_max), C.byref(i)), "rrt_noise_table_create")
+        self.id = i.value
+
+    def info(self):
+        from relativisticraytracer_amd import _lib
+        t, b, boxes = C.c_float(0), C.c_size_t(0), (C.c_int * 12)()
+        _lib.check(_lib.load_test().rrt_noise_table_info(self.id, C.byref(t), C.byref(b), C.byref(boxes)), "rrt_noise_table_info")
+        return {"t_max": t.value, "bytes": b.value, "accretion_box": list(boxes[:6]), "dust_box": list(boxes[6:])}
+
+    def destroy(self):
+        from relativisticraytracer_amd import _lib
+        if self.id:
+            _lib.load_test().rrt_noise_table_destroy(self.id)
+            self.id = 0
+
+
 def unit(name, *args):
-    """Call rrt_unit_<name> through the C ABI; tensors are passed as device pointers."""
+    """Call rrt_unit_<name> (include/rrt_test.h, librrt_hip_test.so) through the C ABI; tensors are passed as device pointers."""
     import torch
     from relativisticraytracer_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_test()
     conv = []
     for a in args:
         if hasattr(a, "data_ptr"):

@@ -9,7 +9,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../include/rrt.h"
+#include "../../include/rrt_test.h"      // rrt.h + the test hooks: the library under test is built with -DRRT_TEST_HOOKS
 
 #define EXPECT(cond)                                                                  \
     do { if (!(cond)) { fprintf(stderr, "host exerciser: %s failed (line %d)\n", #cond, __LINE__); return 1; } } while (0)

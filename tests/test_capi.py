@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def declared_functions():
-    src = open(os.path.join(ROOT, "include", "rrt.h")).read()
+def declared_functions(header="rrt.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"^[ \t]*#[ \t]*define[^\n]*(\\\n[^\n]*)*", "", src, flags=re.M)      # macros (rrt_params_default -> rrt_params_init) are not symbols
     return sorted(set(re.findall(r"\b(rrt_[a-z0-9_]+)\s*\(", src)))
@@ -20,6 +20,7 @@ def test_header_and_binding_table_agree():
     from relativisticraytracer_amd import _lib
     bound = sorted(name for name, _, _ in _lib.SYMBOLS)
     assert declared_functions() == bound
+    assert declared_functions("rrt_test.h") == sorted(name for name, _, _ in _lib.TEST_SYMBOLS)
 
 
 def test_library_exports_every_declared_symbol():
@@ -28,6 +29,28 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(lib, name), name
     assert lib.rrt_abi_version() == 5
+
+
+def test_product_library_exports_no_test_hooks():
+    """rrt_unit_*, rrt_selfcheck_*, rrt_debug_fake_device live in librrt_hip_test.so (the same sources built
+    with -DRRT_TEST_HOOKS, include/rrt_test.h); the product library exports exactly what include/rrt.h declares, the three
+    legacy defaults symbols older binaries call, and launch_raymarch under its two C++ names."""
+    import subprocess
+    from relativisticraytracer_amd import _lib, build
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln)
+    prod, test = exported(build.LIB), exported(build.TEST_LIB)
+    hooks = declared_functions("rrt_test.h")
+    assert len(hooks) == 26 and not [s for s in prod if "unit" in s or "selfcheck" in s or "debug" in s]
+    legacy = ["rrt_get_launch_defaults", "rrt_params_default", "rrt_params_default_v4"]
+    cpp = [s for s in prod if s.startswith("_Z15launch_raymarch")]
+    assert len(cpp) == 2
+    assert prod == sorted(declared_functions() + legacy + cpp)
+    assert test == sorted(prod + hooks)
+    lt = _lib.load_test()
+    for name in hooks + declared_functions():
+        assert hasattr(lt, name), name
 
 
 def test_library_exports_launch_raymarch_as_a_cpp_symbol():
@@ -148,7 +171,7 @@ def test_handles_are_tied_to_their_device_cpu_side():
     the test hook rrt_debug_fake_device()."""
     import relativisticraytracer_amd as rrt
     from relativisticraytracer_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_test()
     try:
         assert lib.rrt_debug_fake_device(0) == 0
         sky = C.c_ulonglong(0)
@@ -321,7 +344,7 @@ def test_test_hooks_are_off_unless_the_process_asked_for_them():
     """rrt_debug_fake_device only works in a process started with RRT_ENABLE_TEST_HOOKS=1 (a stray call must
     not be able to make the device-binding checks lie)."""
     import subprocess, sys
-    code = ("from relativisticraytracer_amd import _lib; lib = _lib.load(); "
+    code = ("from relativisticraytracer_amd import _lib; lib = _lib.load_test(); "
             "import sys; sys.exit(10 + lib.rrt_debug_fake_device(3))")
     import os
     env = dict(os.environ); env.pop("RRT_ENABLE_TEST_HOOKS", None)

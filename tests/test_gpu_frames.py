@@ -1066,49 +1066,52 @@ def test_noise_table_windows_far_along_the_clock(ctx):
         nw.close()
 
 
-def test_handles_are_tied_to_their_device(ctx):
+def test_handles_are_tied_to_their_device(ctx, sky):
     """VERDICT r02 item 7 / ADVICE: a sky, workspace or noise table used while another device is current is
     RRT_ERR_BAD_HANDLE, not a wild device pointer in a kernel.  One GPU here, so "another device" is the test hook
-    rrt_debug_fake_device(); on the real device everything launches."""
+    rrt_debug_fake_device() -- which only librrt_hip_test.so has (round 5), so the whole test talks to that library
+    (_lib.using_test_library: the package's wrappers and the hook then share one set of registries); on the real device
+    everything launches."""
     import ctypes as C
     import torch
     from relativisticraytracer_amd import _lib
-    g, rrt, tex = ctx
-    lib = _lib.load()
-    w, h = 64, 36
-    cam = rrt.CameraState.default(); fx = rrt.CameraEffects()
-    out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
-    nt = rrt.NoiseTable(2.0); ws = rrt.Workspace(64 << 20); order = rrt.TileOrder()
-    real = torch.cuda.current_device()
-    try:
-        assert nt.info()["device"] == real
-        rrt.launch_raymarch(out, w, h, 1.0, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=ws.id, path_policy=2))
-        torch.cuda.synchronize()
-        ref = out.clone()
-        lib.rrt_debug_fake_device(real + 1)
-        for prm in (rrt.RenderParams(spin=0.9), rrt.RenderParams(spin=0.9, noise_table=nt.id)):
-            with pytest.raises(rrt.RRTError) as e:
-                rrt.launch_raymarch(out, w, h, 1.0, cam, tex, fx, prm)
-            assert e.value.status == 4
-        # a sky of the "other" device with a table / pool of this one: each is checked on its own
-        sky2 = C.c_ulonglong(0)
-        assert lib.rrt_sky_create_from_device(C.c_void_p(out.data_ptr()), 8, 4, C.byref(sky2)) == 0      # registered under the fake device
-        a = cam
-        for prm in (rrt.RenderParams(spin=0.9, noise_table=nt.id), rrt.RenderParams(spin=0.9, workspace=ws.id, path_policy=2)):
+    g, rrt, _ = ctx
+    with _lib.using_test_library() as lib:
+        tex = rrt.SkyTexture(sky)
+        w, h = 64, 36
+        cam = rrt.CameraState.default(); fx = rrt.CameraEffects()
+        out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+        nt = rrt.NoiseTable(2.0); ws = rrt.Workspace(64 << 20); order = rrt.TileOrder()
+        real = torch.cuda.current_device()
+        try:
+            assert nt.info()["device"] == real
+            rrt.launch_raymarch(out, w, h, 1.0, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=ws.id, path_policy=2))
+            torch.cuda.synchronize()
+            ref = out.clone()
+            lib.rrt_debug_fake_device(real + 1)
+            for prm in (rrt.RenderParams(spin=0.9), rrt.RenderParams(spin=0.9, noise_table=nt.id)):
+                with pytest.raises(rrt.RRTError) as e:
+                    rrt.launch_raymarch(out, w, h, 1.0, cam, tex, fx, prm)
+                assert e.value.status == 4
+            # a sky of the "other" device with a table / pool of this one: each is checked on its own
+            sky2 = C.c_ulonglong(0)
+            assert lib.rrt_sky_create_from_device(C.c_void_p(out.data_ptr()), 8, 4, C.byref(sky2)) == 0      # registered under the fake device
+            a = cam
+            for prm in (rrt.RenderParams(spin=0.9, noise_table=nt.id), rrt.RenderParams(spin=0.9, workspace=ws.id, path_policy=2)):
+                assert lib.rrt_launch_raymarch(C.c_void_p(out.data_ptr()), w, h, 1.0, C.byref(a), sky2, C.byref(fx), C.byref(prm), None) == 4
+            assert lib.rrt_workspace_stats(ws.id, None, None) == 4
+            assert lib.rrt_tile_order_info(order.id, None, None, None, None, None, 0) == 4
+            prm = rrt.RenderParams(spin=0.9, tile_order=order.id)
             assert lib.rrt_launch_raymarch(C.c_void_p(out.data_ptr()), w, h, 1.0, C.byref(a), sky2, C.byref(fx), C.byref(prm), None) == 4
-        assert lib.rrt_workspace_stats(ws.id, None, None) == 4
-        assert lib.rrt_tile_order_info(order.id, None, None, None, None, None, 0) == 4
-        prm = rrt.RenderParams(spin=0.9, tile_order=order.id)
-        assert lib.rrt_launch_raymarch(C.c_void_p(out.data_ptr()), w, h, 1.0, C.byref(a), sky2, C.byref(fx), C.byref(prm), None) == 4
-        lib.rrt_sky_destroy(sky2)
-        lib.rrt_debug_fake_device(-1)
-        out.zero_()
-        rrt.launch_raymarch(out, w, h, 1.0, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=ws.id, path_policy=2))
-        torch.cuda.synchronize()
-        assert torch.equal(out, ref)
-    finally:
-        lib.rrt_debug_fake_device(-1)
-        nt.destroy(); ws.destroy(); order.destroy()
+            lib.rrt_sky_destroy(sky2)
+            lib.rrt_debug_fake_device(-1)
+            out.zero_()
+            rrt.launch_raymarch(out, w, h, 1.0, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=ws.id, path_policy=2))
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+        finally:
+            lib.rrt_debug_fake_device(-1)
+            nt.destroy(); ws.destroy(); order.destroy(); tex.destroy()
 
 
 def test_cost_ordered_dispatch_renders_the_same_frames(ctx):

@@ -167,7 +167,7 @@ def test_sky_sampler_bitexact(g, po, sky):
     d = rng.normal(size=(1 << 16, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
     d = d.astype(np.float32)
     d[:4] = [[0, 1, 0], [0, -1, 0], [-1, 0, 0], [1, 0, 0]]     # poles and the +-pi seam
-    tex = rrt.SkyTexture(sky)
+    tex = g.HookSky(sky)
     for off in (0.0, 0.005, -0.005):
         for bits in (8, 0):
             out = torch.empty(len(d) * 4, device="cuda")
@@ -228,7 +228,7 @@ def test_noise_table_reads_equal_the_arithmetic_hash(g):
     (incl. their edges); points outside a box are counted and clamped, never read out of bounds."""
     import torch
     import relativisticraytracer_amd as rrt
-    nt = rrt.NoiseTable(8.0)
+    nt = g.HookNoiseTable(8.0)
     try:
         info = nt.info()
         rng = np.random.default_rng(23)
@@ -261,7 +261,7 @@ def test_density_functions_with_table_switches_equal_the_arithmetic_ones(g, po, 
     of a 4K frame produce -- so that the switches really are on; bits must equal the oracle's."""
     import torch
     import relativisticraytracer_amd as rrt
-    nt = rrt.NoiseTable(8.0)
+    nt = g.HookNoiseTable(8.0)
     try:
         rng = np.random.default_rng(29)
         waves = 4096
@@ -317,7 +317,7 @@ def test_early_outs_agree_with_the_literal_densities_through_the_gate(g, po):
     y[3 * q:] = rng.uniform(-4.0, 4.0, n - 3 * q)
     pts = np.stack([rc * np.cos(ang), y, rc * np.sin(ang)], 1).astype(np.float32)
     for t in (0.0, 3.0):
-        nt = rrt.NoiseTable(8.0)
+        nt = g.HookNoiseTable(8.0)
         try:
             d = g.dev(pts)
             got_disk, got_dust = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
@@ -351,7 +351,7 @@ def test_fast_sqrt_is_correctly_rounded_everywhere_it_is_used(g):
     from relativisticraytracer_amd import _lib
     cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
     lo, hi = 0x3f800000, 0x3f800000 + (64 << 23)
-    _lib.check(_lib.load().rrt_selfcheck_sqrt(lo, hi, C.c_void_p(cnt.data_ptr()), None), "selfcheck_sqrt")
+    _lib.check(_lib.load_test().rrt_selfcheck_sqrt(lo, hi, C.c_void_p(cnt.data_ptr()), None), "selfcheck_sqrt")
     torch.cuda.synchronize()
     assert int(cnt[0]) == 0, f"{int(cnt[0])} mismatches, e.g. bits {int(cnt[1]):#x}"
 
@@ -362,7 +362,7 @@ def test_fast_divide_is_correctly_rounded_on_march_operands(g):
     import torch
     from relativisticraytracer_amd import _lib
     cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
-    _lib.check(_lib.load().rrt_selfcheck_div(1 << 35, 12345, C.c_void_p(cnt.data_ptr()), None), "selfcheck_div")
+    _lib.check(_lib.load_test().rrt_selfcheck_div(1 << 35, 12345, C.c_void_p(cnt.data_ptr()), None), "selfcheck_div")
     torch.cuda.synchronize()
     assert int(cnt[0]) == 0, f"{int(cnt[0])} mismatches, e.g. {int(cnt[1]):#x} / {int(cnt[2]):#x}"
 
@@ -379,7 +379,7 @@ def test_divide_with_the_marchs_own_seeds(g):
     import torch
     from relativisticraytracer_amd import _lib
     cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
-    _lib.check(_lib.load().rrt_selfcheck_div_march(1 << 33, 2026, 1.45e-4, 8.9e-3, C.c_void_p(cnt.data_ptr()), None), "selfcheck_div_march")
+    _lib.check(_lib.load_test().rrt_selfcheck_div_march(1 << 33, 2026, 1.45e-4, 8.9e-3, C.c_void_p(cnt.data_ptr()), None), "selfcheck_div_march")
     torch.cuda.synchronize()
     assert int(cnt[2]) == 0, f"{int(cnt[2])} divide mismatches, e.g. {int(cnt[6]):#x} / {int(cnt[7]):#x}"
     assert int(cnt[3]) > 1.5 * (1 << 33), int(cnt[3])              # most roots were accepted, two divides each
@@ -397,7 +397,7 @@ def test_seeded_roots_around_the_powers_of_two_under_a_dense_seed_sweep(g):
     import torch
     from relativisticraytracer_amd import _lib
     cnt = torch.zeros(6, dtype=torch.int64, device="cuda")
-    _lib.check(_lib.load().rrt_selfcheck_sqrt_boundaries(0, 30, 64, 1 << 14, 1.45e-4, 8.9e-3, C.c_void_p(cnt.data_ptr()), None), "selfcheck_sqrt_boundaries")
+    _lib.check(_lib.load_test().rrt_selfcheck_sqrt_boundaries(0, 30, 64, 1 << 14, 1.45e-4, 8.9e-3, C.c_void_p(cnt.data_ptr()), None), "selfcheck_sqrt_boundaries")
     torch.cuda.synchronize()
     assert int(cnt[0]) == 0 and int(cnt[1]) == 0, f"{int(cnt[0])} + {int(cnt[1])} mismatches, e.g. x bits {int(cnt[4]):#x} seed bits {int(cnt[5]):#x}"
     n = 30 * 129 * (1 << 14) * 2
@@ -449,7 +449,7 @@ def test_seeded_sqrt_is_correctly_rounded_whenever_it_accepts(g):
     from relativisticraytracer_amd import _lib
     for lo in (0x3f800000, 0x3f800000 + (14 << 23)):
         cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
-        _lib.check(_lib.load().rrt_selfcheck_sqrt_seeded(lo, lo + (2 << 23), C.c_void_p(cnt.data_ptr()), None), "selfcheck_sqrt_seeded")
+        _lib.check(_lib.load_test().rrt_selfcheck_sqrt_seeded(lo, lo + (2 << 23), C.c_void_p(cnt.data_ptr()), None), "selfcheck_sqrt_seeded")
         torch.cuda.synchronize()
         assert int(cnt[0]) == 0, f"{int(cnt[0])} mismatches, e.g. x bits {int(cnt[1]):#x} seed bits {int(cnt[2]):#x}"
         n = 2 << 23
@@ -467,11 +467,11 @@ def test_media_sqrt_and_divide_cores_are_correctly_rounded(g):
     from relativisticraytracer_amd import _lib
     cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
     lo, hi = 0x3f800000 - (40 << 23), 0x3f800000
-    _lib.check(_lib.load().rrt_selfcheck_sqrt(lo, hi, C.c_void_p(cnt.data_ptr()), None), "selfcheck_sqrt")
+    _lib.check(_lib.load_test().rrt_selfcheck_sqrt(lo, hi, C.c_void_p(cnt.data_ptr()), None), "selfcheck_sqrt")
     torch.cuda.synchronize()
     assert int(cnt[0]) == 0, f"sqrt: {int(cnt[0])} mismatches, e.g. bits {int(cnt[1]):#x}"
     cnt.zero_()
-    _lib.check(_lib.load().rrt_selfcheck_div_tame(1 << 32, 777, C.c_void_p(cnt.data_ptr()), None), "selfcheck_div_tame")
+    _lib.check(_lib.load_test().rrt_selfcheck_div_tame(1 << 32, 777, C.c_void_p(cnt.data_ptr()), None), "selfcheck_div_tame")
     torch.cuda.synchronize()
     assert int(cnt[0]) == 0, f"div: {int(cnt[0])} mismatches, e.g. {int(cnt[1]):#x} / {int(cnt[2]):#x}"
 
@@ -485,7 +485,7 @@ def test_division_by_compile_time_constants_is_correctly_rounded(g):
     from relativisticraytracer_amd import _lib
     cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
     lo, hi = (127 - 40) << 23, (127 + 40) << 23
-    _lib.check(_lib.load().rrt_selfcheck_div_const(lo, hi, C.c_void_p(cnt.data_ptr()), None), "selfcheck_div_const")
+    _lib.check(_lib.load_test().rrt_selfcheck_div_const(lo, hi, C.c_void_p(cnt.data_ptr()), None), "selfcheck_div_const")
     torch.cuda.synchronize()
     assert int(cnt[0]) == 0, f"{int(cnt[0])} mismatches, e.g. dividend bits {int(cnt[1]):#x} with constant #{int(cnt[2])}"
 
@@ -495,5 +495,5 @@ def test_unit_kernels_empty_and_bad_args(g):
     from relativisticraytracer_amd import _lib
     z = torch.empty(0, device="cuda")
     g.unit("hash31", 0, z, z)                         # n = 0 is a no-op
-    assert _lib.load().rrt_unit_hash31(4, None, None, None) == 1        # RRT_ERR_INVALID_ARGUMENT
-    assert _lib.load().rrt_unit_fbm(4, z.data_ptr(), 99, z.data_ptr(), None) == 1
+    assert _lib.load_test().rrt_unit_hash31(4, None, None, None) == 1        # RRT_ERR_INVALID_ARGUMENT
+    assert _lib.load_test().rrt_unit_fbm(4, z.data_ptr(), 99, z.data_ptr(), None) == 1

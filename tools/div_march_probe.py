@@ -5,7 +5,7 @@ import ctypes as C, os, sys, time
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from relativisticraytracer_amd import _lib
-lib = _lib.load()
+lib = _lib.load_test()
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 chunk = 1 << 36
 for tol1, tol2 in ((1.45e-4, 8.9e-3), (1.0e-4, 6.0e-3), (7.0e-5, 4.5e-3), (3.0e-5, 2.0e-3), (1.0e-5, 5.0e-4)):

@@ -5,7 +5,7 @@ import ctypes as C, os, sys, time
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from relativisticraytracer_amd import _lib
-lib = _lib.load()
+lib = _lib.load_test()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 34
 cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
 t0 = time.time()
