@@ -555,10 +555,33 @@ def main():
                                  time_=14.0)
             heavy["per_ray_means"] = {k: round(v, 2) for k, v in hm.items()}
             heavy["ops_per_ray"] = round(ops_per_ray(hm["steps"], hm["n_noise"], hm["n_dens"], hm["n_samples"]), 1)
-            for tag in ("arithmetic_noise", "noise_table", "noise_table_cost_ordered", "noise_table_first_frame_probe_ordered"):
+            # counters of this view's kernels: issue-slot utilisation and HBM bytes from rocprofv3 PMC passes
+            # (tools/pass_counters.sh), quoted only if the record was measured on THIS build's kernel sources
+            pc_note = "not measured for this build: run tools/pass_counters.sh + tools/summarize_pass_counters.py"
+            pcs = {}
+            ppath = os.path.join(ROOT, "profiles", "pass_counters.json")
+            if os.path.exists(ppath):
+                try:
+                    pj = json.load(open(ppath))
+                    if pj.get("source_hash") == source_hash():
+                        pcs = pj.get("runs", {})
+                        pc_note = "rocprofv3 PMC, " + str(pj.get("from", "profiles/")) + "; " + str(pj.get("note", ""))
+                    else:
+                        pc_note = "profiles/pass_counters.json is from another build; not used"
+                except Exception:
+                    pcs = {}
+            for tag, run in (("arithmetic_noise", None), ("noise_table", "skimmer/single"), ("noise_table_cost_ordered", "skimmer/single_ordered"),
+                             ("noise_table_first_frame_probe_ordered", None)):
                 if tag in heavy:
-                    heavy[tag]["valu_roofline_frac"] = round(heavy["ops_per_ray"] * rays / (heavy[tag]["ms_per_step"] * 1e-3) / 1e12
-                                                             / VALU_PEAK_TOPS, 4)
+                    k = pcs.get(run, {}).get("raymarch_pixels") if run else None
+                    heavy[tag]["issue_slot_util"] = k.get("issue_slot_util") if k else None
+                    heavy[tag]["traffic_bytes"] = k.get("hbm_bytes_upper") if k else None
+                    heavy[tag]["source_ops_per_s_over_2p4ghz_peak"] = round(heavy["ops_per_ray"] * rays / (heavy[tag]["ms_per_step"] * 1e-3) / 1e12
+                                                                            / VALU_PEAK_TOPS, 4)
+            heavy["counters_note"] = pc_note + ("  (source_ops_per_s_over_2p4ghz_peak is a FORMULA -- SURVEY 8d's source operations, which price 223 per "
+                                                "noise3D that the tables replace by loads -- not a utilisation; it can exceed 1)")
+            if "skimmer/shard0of8" in pcs:
+                heavy["rank_share_three_pass_kernels"] = pcs["skimmer/shard0of8"]
         line = {
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

@@ -238,10 +238,11 @@ int rrt_tile_order_info(int id, unsigned long long* launches, unsigned long long
  *      arithmetic (a few milliseconds).  Caller-owned like the sky and tied to the device it was created on; any
  *      number of launches / streams of that device may read one table concurrently.  A launch whose `time` lies
  *      outside the window renders with the arithmetic kernels: same bytes, slower.
- *      Size: 0.49 GB for [0, 32 s] at full coverage.  It does not stay bounded as the window slides along the
- *      reference's unbounded simTime (main.cpp:515): the dust coordinates shear with time * (10/rc)^1.5
- *      (densities.h:88-93), so the z extent of the box grows like 0.75 t0 + (t1 - t0).  Hence two knobs: the window
- *      and the coverage -- which call families are table-served; the finest ones dominate the volume:
+ *      Size: 0.49 GB for [0, 32 s] at full coverage.  A single dense box does not stay bounded as the window slides along
+ *      the reference's unbounded simTime (main.cpp:515): the dust coordinates shear with time * (10/rc)^1.5
+ *      (densities.h:88-93), so its z extent grows like 0.75 t0 + (t1 - t0); far along the clock the fine dust families
+ *      therefore move to the BANDED layout (below), which keeps a 10 s window at t = 500 s at full coverage inside 2 GiB.
+ *      Two more knobs: the window and the coverage -- which call families are table-served; the finest ones dominate the volume:
  *          RRT_TABLE_FULL      all table-served families
  *          RRT_TABLE_COARSE    without the 4.41 and 4.0 cells-per-unit dust families (about 1/9 of the dust box)
  *          RRT_TABLE_COARSEST  also without the 2.1 dust family and the finest accretion octave
@@ -249,7 +250,15 @@ int rrt_tile_order_info(int id, unsigned long long* launches, unsigned long long
  *      coverage, within a byte budget (*bytes_out == 0: nothing fits, render without a table).
  *      rrt_noise_table_plan*() is host arithmetic only and returns the same RRT_ERR_INVALID_ARGUMENT as create for a
  *      box that cannot be addressed (>= 2^28 lattice points). ---- */
-enum { RRT_TABLE_FULL = 0, RRT_TABLE_COARSE = 1, RRT_TABLE_COARSEST = 2 };
+enum { RRT_TABLE_FULL = 0, RRT_TABLE_COARSE = 1, RRT_TABLE_COARSEST = 2,
+       /* LAYOUT of the dust families (ABI 5), ORed into `coverage` to force one; neither = automatic.  DENSE: one box for all
+        * of them -- what every window near the origin of the clock gets.  BANDED: the three fine families (ridge octaves 1 and
+        * 2, the detail octave -- the ones that make the dense box unaddressable minutes into the clock) in one small box per
+        * band of the angular rate omega = (10/rc)^1.5, picked per sample from its own radius: the shear of densities.h:88-93
+        * only costs every band ITS OWN z range.  [495, 505 s] at full coverage: not addressable dense, ~1.5 GB banded.
+        * Same bytes.  Automatic: dense unless it is unaddressable, or over 768 MB and larger than the banded plan.
+        * rrt_noise_table_window() reports the layout a table got in this bit of its `coverage`. */
+       RRT_TABLE_BANDED = 16, RRT_TABLE_DENSE = 32 };
 int rrt_noise_table_create(float t_max, int* out_id);                                  /* = window [0, t_max], full coverage */
 int rrt_noise_table_create_window(float t0, float t1, int coverage, int* out_id);
 int rrt_noise_table_destroy(int id);
@@ -257,6 +266,12 @@ int rrt_noise_table_info(int id, float* t_max, size_t* bytes, int* boxes12);   /
 int rrt_noise_table_window(int id, float* t0, float* t1, int* coverage, int* device);
 int rrt_noise_table_plan(float t_max, size_t* bytes, int* boxes12);
 int rrt_noise_table_plan_window(float t0, float t1, int coverage, size_t* bytes, int* boxes12);
+/* the layout such a table gets (host arithmetic): *banded = 0 / 1; for a banded one the number of omega bands, the rule
+ * band = clamp((int)((omega - w_min) * w_scale)), the box (x0, y0, z0, nx, ny, nz) of every (family, band) -- family 0 / 1 / 2
+ * = ridge octave 1 / ridge octave 2 / detail octave, band_boxes[(family * cap_bands + band) * 6 ...], cap_bands >= n_bands
+ * (64 always is) -- and of the four accretion octaves (acc_octave_boxes[24]).  Either array may be NULL. */
+int rrt_noise_table_plan_layout(float t0, float t1, int coverage, int* banded, int* n_bands, float* w_min, float* w_scale,
+                                int32_t* band_boxes, int cap_bands, int32_t* acc_octave_boxes);
 int rrt_noise_table_fit_window(float t_from, float t_until, size_t budget_bytes, float* t1_out, int* coverage_out, size_t* bytes_out);
 
 /* Handles and devices: a sky, workspace or noise table belongs to the HIP device that was current when it was

@@ -296,6 +296,7 @@ def clock_probe_ghz(duration_us=20000, stream=None):
 
 
 TABLE_FULL, TABLE_COARSE, TABLE_COARSEST = 0, 1, 2      # rrt.h: which noise call families a table serves
+TABLE_BANDED, TABLE_DENSE = 16, 32                        # ... ORed in: force a layout of the dust families (default: automatic)
 
 
 class NoiseTable:
@@ -334,6 +335,19 @@ class NoiseTable:
                    "rrt_noise_table_plan_window")
         return {"t_max": float(t_max), "t0": float(t0), "coverage": int(coverage), "bytes": b.value,
                 "accretion_box": list(box[:6]), "dust_box": list(box[6:])}
+
+    @staticmethod
+    def plan_layout(t_max, t0=0.0, coverage=TABLE_FULL):
+        """Host arithmetic only: {"banded": bool} and, for a banded table, "n_bands", "w_min", "w_scale", "band_boxes"
+        (3, n_bands, 6) -- ridge octave 1, ridge octave 2, detail octave -- and "acc_octave_boxes" (4, 6)."""
+        banded, nb, w0, ws = C.c_int(0), C.c_int(0), C.c_float(0), C.c_float(0)
+        boxes = np.zeros((3, 64, 6), np.int32); acc = np.zeros((4, 6), np.int32)
+        _lib.check(_lib.load().rrt_noise_table_plan_layout(float(t0), float(t_max), int(coverage), C.byref(banded), C.byref(nb), C.byref(w0),
+                                                           C.byref(ws), boxes.ctypes.data, 64, acc.ctypes.data), "rrt_noise_table_plan_layout")
+        if not banded.value:
+            return {"banded": False}
+        return {"banded": True, "n_bands": nb.value, "w_min": w0.value, "w_scale": ws.value,
+                "band_boxes": boxes[:, :nb.value].copy(), "acc_octave_boxes": acc}
 
     @staticmethod
     def fit(t_from, t_until, budget_bytes):

@@ -92,6 +92,7 @@ SYMBOLS = [
     ("rrt_noise_table_create_window", _i, [_f, _f, _i, C.POINTER(_i)]),
     ("rrt_noise_table_window", _i, [_i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_i), C.POINTER(_i)]),
     ("rrt_noise_table_plan_window", _i, [_f, _f, _i, C.POINTER(C.c_size_t), C.POINTER(_i * 12)]),
+    ("rrt_noise_table_plan_layout", _i, [_f, _f, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f), _vp, _i, _vp]),
     ("rrt_noise_table_fit_window", _i, [_f, _f, C.c_size_t, C.POINTER(_f), C.POINTER(_i), C.POINTER(C.c_size_t)]),
     ("rrt_set_launch_defaults", _i, [_prm]),
     ("rrt_get_launch_defaults_sized", _i, [_vp, C.c_uint32]),

@@ -222,6 +222,47 @@ RRT_DEV float lut_blend(const LutTap& t) {
 }
 RRT_DEV float noise3d_lut(const NoiseLut& L, v3 p, unsigned* oob) { return lut_blend(lut_fetch(L, p, oob)); }
 
+/*
+ * BANDED layout of the fine dust families (round 5; rrt_noise_table with RRT_TABLE_BANDED, MEDIA == 3 in the kernels).
+ * The dust coordinates shear with time * omega(rc), omega = (10/rc)^1.5 in [0.253, 1] (densities.h:88-93: differential
+ * rotation), so the z extent of ONE dense box over all radii grows like 0.75 t0 and is unaddressable at full coverage a few
+ * minutes into the reference's unbounded clock (main.cpp:515) -- although a sample only ever touches the z range of ITS OWN
+ * radius.  The three families that dominate the volume (ridge octaves 1 and 2 at 2.1 and 4.41 cells per unit, the detail
+ * octave at 4.0) therefore get one small dense box per BAND of omega: a sample picks its band from its own omega (which it
+ * has: `kepler`), reads that band's box geometry (one 32-byte record per family, a per-lane load that hits L1), and looks
+ * its cells up exactly as before.  Bands are uniform in omega, which makes their z extents equal (width ~ t * d omega).
+ * [495, 505 s] at full coverage: unaddressable dense (3.4 GB for ridge octave 2 alone), ~1.5 GB banded.  Same bits: the
+ * records are the same hash31 values.  The coarse families (both warps, ridge octave 0) stay in the one dense box.
+ */
+struct BandLut { unsigned cell0; int origin; int nx, nxy; unsigned last; unsigned pad[3]; };      /* 32 bytes */
+struct DustBands {
+    const BandLut* entries;        /* [family 0..2][band]; family 0 = ridge octave 1, 1 = ridge octave 2, 2 = detail octave 0;
+                                      then kLutAccOctaves records: the ACCRETION table's octaves, one box each (below) */
+    int n_bands;
+    float w_min, w_scale;          /* band = clamp((int)((omega - w_min) * w_scale), 0, n_bands - 1) */
+};
+constexpr int kBandFamilies = 3;
+/* The same layout splits the accretion table by OCTAVE: its y coordinate drifts with 0.35 t and fbm scales it by 2.05 per
+ * octave (densities.h:44-54, math_utils.h:116), so at t = 500 s the four table-served octaves sit at y ~ 175, 370, 770 and
+ * 1580 -- one box over all of them is 1 500 cells tall (0.96 GB) where each octave needs at most 160 (0.1 GB together). */
+RRT_DEV int dust_band(const DustBands& B, float omega) {
+    const int b = (int)((omega - B.w_min) * B.w_scale);
+    return b < 0 ? 0 : (b >= B.n_bands ? B.n_bands - 1 : b);
+}
+/* the box of (family, band) as a NoiseLut whose fields are per-lane values; `table` = the allocation's first cell */
+RRT_DEV NoiseLut record_lut(const float4* table, const BandLut& e, unsigned families) {
+    NoiseLut L;
+    L.cells = table + e.cell0;
+    L.origin = e.origin; L.nx = e.nx; L.nxy = e.nxy; L.last = e.last; L.families = families;
+    return L;
+}
+RRT_DEV NoiseLut band_lut(const NoiseLut& acc0, const NoiseLut& dust, const DustBands& B, int family, int band) {
+    return record_lut(acc0.cells, B.entries[family * B.n_bands + band], dust.families);    /* acc0.cells: the table starts with accretion octave 0 */
+}
+RRT_DEV NoiseLut acc_octave_lut(const NoiseLut& acc0, const DustBands& B, int octave) {
+    return record_lut(acc0.cells, B.entries[kBandFamilies * B.n_bands + octave], acc0.families);
+}
+
 /* Per-lane distance (in lattice cells at scale 1, x weighted 1/4: a 128-byte line holds 8 x-neighbours) of
  * this lane's noise-space point from the first active lane's; lut_fits(spread, s) is wave-uniform: at `s`
  * cells per unit all active lanes stay within kLutCells cells of each other. */
@@ -798,17 +839,20 @@ RRT_DEV float noise3d_sel(v3 p, const NoiseLut& L, bool from_table, unsigned* oo
 #define RRT_LUT_PAIRS 1
 #endif
 
-RRT_DEV void noise3d_lut_pair(const NoiseLut& L, v3 p0, v3 p1, unsigned* oob, float& n0, float& n1) {
+RRT_DEV void noise3d_lut_pair2(const NoiseLut& L0, const NoiseLut& L1, v3 p0, v3 p1, unsigned* oob, float& n0, float& n1) {
     if (RRT_PROBE & 8) { n0 = 0.45f + 0.01f * p0.x; n1 = 0.45f + 0.01f * p1.x; return; }
-    const LutTap a = lut_fetch(L, p0, oob);
-    const LutTap b = lut_fetch(L, p1, oob);
+    const LutTap a = lut_fetch(L0, p0, oob);
+    const LutTap b = lut_fetch(L1, p1, oob);
     n0 = lut_blend(a);
     n1 = lut_blend(b);
+}
+RRT_DEV void noise3d_lut_pair(const NoiseLut& L, v3 p0, v3 p1, unsigned* oob, float& n0, float& n1) {
+    noise3d_lut_pair2(L, L, p0, p1, oob, n0, n1);
 }
 
 /* fbm(p, 2) (math_utils.h:112-121) with a table switch per octave */
 template <bool LUT>
-RRT_DEV float fbm2_sel(v3 p, const NoiseLut& L, bool t0, bool t1, unsigned* oob) {
+RRT_DEV float fbm2_sel(v3 p, const NoiseLut& L, bool t0, bool t1, unsigned* oob) {      /* (octave 1 from L's own box when t1) */
     float v = 0.0f, a = 0.5f;
     if (LUT && RRT_LUT_PAIRS && t0 && t1) {
         float n0, n1;
@@ -872,8 +916,8 @@ RRT_DEV float disk_azimuth(v3 p, DiskPoint& d) {
     return d.azimuth;
 }
 
-template <bool EARLY_OUT, bool LUT>
-RRT_DEV float accretion_density_at(v3 p, float time, DiskPoint& dp, const NoiseLut& L, unsigned* oob) {
+template <bool EARLY_OUT, bool LUT, bool BANDED = false>
+RRT_DEV float accretion_density_at(v3 p, float time, DiskPoint& dp, const NoiseLut& L, unsigned* oob, const DustBands* bands = nullptr) {
     /* The render kernels (EARLY_OUT) call this only inside the disk zone, |y| < 4 and r < 30 (raymarcher.cu:57), so
      * every division / square root below has tame operands once the radial gate has passed: rc in [10, 25],
      * q = 10/rc in [0.4, 1], thick in [0.5, 0.8], y*y < 16 (a y*y too small for the bare division to be exact,
@@ -932,12 +976,15 @@ RRT_PRAGMA_UNROLL(RRT_ACC_UNROLL)
         if (LUT && RRT_LUT_PAIRS && ((from_table >> o) & 3u) == 3u) {     /* this octave and the next: one round trip */
             const v3 at1 = mk(at.x * 2.05f + 10.0f, at.y * 2.05f + 10.0f, at.z * 2.05f + 10.0f);
             float n0, n1;
-            noise3d_lut_pair(L, at, at1, oob, n0, n1);
+            if (BANDED) noise3d_lut_pair2(acc_octave_lut(L, *bands, o), acc_octave_lut(L, *bands, o + 1), at, at1, oob, n0, n1);
+            else noise3d_lut_pair(L, at, at1, oob, n0, n1);
             n += amp * n0;
             amp *= 0.5f;
             n += amp * n1;
             at = at1;
             ++o;
+        } else if (BANDED && LUT && ((from_table >> o) & 1u)) {
+            n += amp * noise3d_sel<LUT>(at, acc_octave_lut(L, *bands, o), true, oob);
         } else {
             n += amp * noise3d_sel<LUT>(at, L, (from_table >> o) & 1u, oob);
         }
@@ -958,8 +1005,9 @@ RRT_DEV float accretion_density(v3 p, float time, const NoiseLut& L, unsigned* o
 
 /* getDustCloudDensity, densities.h:69-132.  LEAN (the render kernels, which call it only inside the cloud zone
  * |y| < 0.75, r < 25: raymarcher.cu:58): the same tame-operand argument as in accretion_density. */
-template <bool LUT, bool LEAN = true>
-RRT_DEV float dust_density_at(v3 p, float time, DiskPoint& dp, const NoiseLut& L, unsigned* oob) {
+template <bool LUT, bool LEAN = true, bool BANDED = false>
+RRT_DEV float dust_density_at(v3 p, float time, DiskPoint& dp, const NoiseLut& L, unsigned* oob, const DustBands* bands = nullptr,
+                              const NoiseLut* acc0 = nullptr) {
     const float rc = dp.rc, q = dp.q;
     const float outer = smoothstep_t<LEAN>(kDiskOut, kDiskOut * 0.8f, rc);
     const float inner = smoothstep_t<LEAN>(kIsco, kIsco + 5.0f, rc);
@@ -1018,6 +1066,9 @@ RRT_PRAGMA_UNROLL(RRT_WARP_UNROLL)
     }
     const v3 fc = add(sc, mul(mk(vx, vy, vz), 1.5f));              /* `final_coords`, :108 */
 
+    /* BANDED: the boxes of ridge octaves 1, 2 and of the detail octave are those of this sample's omega band */
+    const int band = BANDED ? dust_band(*bands, kepler) : 0;
+
     float n = 0.0f, amp = 1.0f, freq = 1.0f;                       /* ridged sum, :111-120 */
     const unsigned ridge_bits = (from_table >> 4) & ((1u << kLutRidgeOctaves) - 1u);
 RRT_PRAGMA_UNROLL(RRT_RIDGE_UNROLL)
@@ -1029,14 +1080,21 @@ RRT_PRAGMA_UNROLL(RRT_RIDGE_UNROLL)
         if (LEAN && k > 0 && n + 2.0f * amp <= 0.7272f) return 0.0f;
         if (LUT && RRT_LUT_PAIRS && ((ridge_bits >> k) & 3u) == 3u) {
             float n0, n1;
-            noise3d_lut_pair(L, mul(fc, freq), mul(fc, freq * 2.1f), oob, n0, n1);
+            if (BANDED) {                                          /* octave k from its own box, k + 1 (1 or 2) from its band's */
+                const NoiseLut La = k == 0 ? L : band_lut(*acc0, L, *bands, k - 1, band);
+                noise3d_lut_pair2(La, band_lut(*acc0, L, *bands, k, band), mul(fc, freq), mul(fc, freq * 2.1f), oob, n0, n1);
+            } else {
+                noise3d_lut_pair(L, mul(fc, freq), mul(fc, freq * 2.1f), oob, n0, n1);
+            }
             n += (1.0f - fabsf(n0 * 2.0f - 1.0f)) * amp;
             amp *= 0.5f;
             freq *= 2.1f;
             n += (1.0f - fabsf(n1 * 2.0f - 1.0f)) * amp;
             ++k;
         } else {
-            const float nv = noise3d_sel<LUT>(mul(fc, freq), L, (ridge_bits >> k) & 1u, oob);
+            float nv;
+            if (BANDED && LUT && k >= 1 && k <= 2 && ((ridge_bits >> k) & 1u)) nv = noise3d_sel<LUT>(mul(fc, freq), band_lut(*acc0, L, *bands, k - 1, band), true, oob);
+            else nv = noise3d_sel<LUT>(mul(fc, freq), L, (ridge_bits >> k) & 1u, oob);
             const float wisp = 1.0f - fabsf(nv * 2.0f - 1.0f);
             n += wisp * amp;
         }
@@ -1050,7 +1108,9 @@ RRT_PRAGMA_UNROLL(RRT_RIDGE_UNROLL)
      * caller's `d_cloud > 0.001f` gates (raymarcher.cu:71,91) discard it whatever the detail noise is. */
     if (LEAN && envelope * strands <= 9.25e-5f) return 0.0f;
     const v3 dc = mul(fc, 4.0f);
-    const float detail = fbm2_sel<LUT>(mk(dc.x + 0.0f, dc.y + time * 0.5f, dc.z + 0.0f), L, from_table & 256u, false, oob);
+    const float detail = (BANDED && LUT && (from_table & 256u))
+        ? fbm2_sel<LUT>(mk(dc.x + 0.0f, dc.y + time * 0.5f, dc.z + 0.0f), band_lut(*acc0, L, *bands, 2, band), true, false, oob)
+        : fbm2_sel<LUT>(mk(dc.x + 0.0f, dc.y + time * 0.5f, dc.z + 0.0f), L, from_table & 256u, false, oob);
     strands *= (0.6f + 0.4f * detail);
     return envelope * strands * 12.0f;
 }
@@ -1058,7 +1118,7 @@ template <bool LUT, bool LEAN = true>
 RRT_DEV float dust_density(v3 p, float time, const NoiseLut& L, unsigned* oob) {
     DiskPoint dp;
     if (!disk_point<LEAN>(p, dp)) return 0.0f;
-    return dust_density_at<LUT, LEAN>(p, time, dp, L, oob);
+    return dust_density_at<LUT, LEAN, false>(p, time, dp, L, oob);
 }
 
 /* Both densities of one in-zone sample as the render kernels need them (raymarcher.cu:68-69): the position-only
@@ -1071,14 +1131,15 @@ RRT_DEV float dust_density(v3 p, float time, const NoiseLut& L, unsigned* oob) {
  * these values) tests the gate and nothing else.  A new consumer of the raw densities -- a debug density output, say --
  * must call the literal instantiations (EARLY_OUT / LEAN = false).  Pinned by tests/test_gpu_units.py::
  * test_early_outs_agree_with_the_literal_densities_through_the_gate on points straddling every threshold. */
-template <bool LUT>
+/* MEDIA as in the kernels: 1 = arithmetic noise, 2 = dense lattice-hash tables, 3 = tables with the fine dust families banded */
+template <int MEDIA>
 RRT_DEV void media_densities(v3 p, float time, bool in_disk, bool in_cloud, const NoiseLut& lut_acc, const NoiseLut& lut_dust,
-                             unsigned* oob, float& d_disk, float& d_cloud) {
+                             const DustBands& bands, unsigned* oob, float& d_disk, float& d_cloud) {
     d_disk = 0.0f; d_cloud = 0.0f;
     DiskPoint dp;
     if (!disk_point<true>(p, dp)) return;
-    if (in_disk && !(RRT_PROBE & 1)) d_disk = accretion_density_at<true, LUT>(p, time, dp, lut_acc, oob);
-    if (in_cloud && !(RRT_PROBE & 2)) d_cloud = dust_density_at<LUT, true>(p, time, dp, lut_dust, oob);
+    if (in_disk && !(RRT_PROBE & 1)) d_disk = accretion_density_at<true, MEDIA >= 2, MEDIA == 3>(p, time, dp, lut_acc, oob, &bands);
+    if (in_cloud && !(RRT_PROBE & 2)) d_cloud = dust_density_at<MEDIA >= 2, true, MEDIA == 3>(p, time, dp, lut_dust, oob, &bands, &lut_acc);
 }
 
 /* ---- radiative transfer of one in-zone sample, raymarcher.cu:67-117 ---- */

@@ -127,8 +127,23 @@ int g_ws_next = 1;
  * (layout and use: NoiseLut in rrt_device.h).  The boxes are computed on the host from the coordinate ranges
  * those calls can reach for t0 <= time <= t1 (lut_boxes below); a launch with a time outside that window
  * simply runs the arithmetic kernels. */
+constexpr int kMaxBands = 64;
+/* BANDED layout (round 5; rrt_device.h: DustBands): the three fine dust families in one small box per omega band */
+struct BandPlan {
+    int n_bands;                                   /* 0: dense layout */
+    float w_min, w_scale;
+    bool present[rrt::kBandFamilies];              /* family in the table's coverage */
+    LutBox box[rrt::kBandFamilies][kMaxBands];
+    unsigned cell0[rrt::kBandFamilies][kMaxBands]; /* first cell of the box, in cells from d_cells */
+    LutBox acc_box[rrt::kLutAccOctaves];           /* the accretion table, one box per octave (octave 0 first in the allocation) */
+    unsigned acc_cell0[rrt::kLutAccOctaves];
+    unsigned dust_cell0;                           /* the coarse dust families' box */
+    size_t entries_offset;                         /* byte offset of the BandLut array inside the allocation */
+};
 struct NoiseTableObject {
-    float4* d_cells;          /* accretion box, then dust box */
+    float4* d_cells;          /* dense: accretion box, dust box.  banded: accretion octave boxes, the coarse dust families' box, the band boxes, the BandLut records */
+    bool banded;
+    BandPlan bands;
     size_t bytes;
     float t0, t1;             /* launches with t0 <= time <= t1 read the table */
     int coverage;             /* RRT_TABLE_FULL / _COARSE / _COARSEST */
@@ -239,23 +254,139 @@ void lut_boxes(double t0, double t1, unsigned acc_fam, unsigned dust_fam, LutBox
     }
 }
 
+/* the accretion table's octave `o` alone (banded layout): lut_boxes' first block, one octave instead of their union */
+LutBox acc_octave_box(double t0, double t1, int o) {
+    const double slack = 1e-6 * (std::fabs(t0) + std::fabs(t1)) + 1e-3;
+    Interval c[3] = {Interval{-25.0, 25.0}.scaled(0.45).widened(1e-3),
+                     Interval{-16.0, 16.0}.scaled(0.45).shifted(0.35 * t0, 0.35 * t1).widened(slack),
+                     Interval{-25.0, 25.0}.scaled(0.45).widened(1e-3)};
+    for (int k = 0; k < o; ++k)
+        for (int ax = 0; ax < 3; ++ax) c[ax] = c[ax].scaled(2.05).shifted(10.0, 10.0);
+    Reach r;
+    r.add(c);
+    return r.box();
+}
+
 /* noise3d_lut multiplies with 24-bit operands and addresses records with 32-bit byte offsets */
 bool lut_box_addressable(const LutBox& b) {
     const size_t n = (size_t)b.nx * b.ny * b.nz;
     return (size_t)b.nx * b.ny < ((size_t)1 << 23) && n < ((size_t)1 << 28) && b.nz < (1 << 23);
 }
 
-/* boxes + byte size of a table over [t0, t1] at `coverage`; RRT_ERR_INVALID_ARGUMENT for what create would refuse */
-int plan_table(float t0, float t1, int coverage, NoiseTableObject& nt) {
+/* The fine dust families (bits of the `from_table` word: ridge octave 1, ridge octave 2, detail octave 0), their scales, and
+ * the box of one of them for samples whose omega = (10/rc)^1.5 lies in [wa, wb]: the same interval arithmetic as lut_boxes,
+ * with the radius and the shear restricted to the band. */
+constexpr unsigned kFineDustBits[rrt::kBandFamilies] = {1u << 5, 1u << 6, 256u};
+constexpr unsigned kFineDustMask = (1u << 5) | (1u << 6) | 256u;
+LutBox band_box(int family, double t0, double t1, double wa, double wb) {
+    const double pi = 3.14159265358979 + 1e-5;
+    const double slack = 1e-6 * (std::fabs(t0) + std::fabs(t1)) + 1e-3;
+    wa = std::fmax(wa, 0.25); wb = std::fmin(wb, 1.0);
+    const double rc_lo = std::fmax(10.0, 10.0 / std::pow(wb, 2.0 / 3.0)) - 1e-3, rc_hi = std::fmin(25.0, 10.0 / std::pow(wa, 2.0 / 3.0)) + 1e-3;
+    const double tw[4] = {t0 * wa, t0 * wb, t1 * wa, t1 * wb};
+    const double tw_min = std::fmin(std::fmin(tw[0], tw[1]), std::fmin(tw[2], tw[3])), tw_max = std::fmax(std::fmax(tw[0], tw[1]), std::fmax(tw[2], tw[3]));
+    const Interval sc[3] = {Interval{0.8 * rc_lo, 0.8 * rc_hi}.widened(1e-3), Interval{-11.25, 11.25}.widened(1e-3),
+                            Interval{-(pi + tw_max) * 10.0, (pi - tw_min) * 10.0}.widened(1e-2 + 10.0 * slack)};
+    const double freq = family == 0 ? 2.1 : (family == 1 ? 2.1 * 2.1 : 4.0);
+    Interval c[3];
+    for (int ax = 0; ax < 3; ++ax) c[ax] = sc[ax].widened(1.5 * 0.76).scaled(freq);       /* (coords + 1.5 w2) * freq, densities.h:108-128 */
+    if (family == 2) c[1] = c[1].shifted(0.5 * t0, 0.5 * t1).widened(slack);               /* + (0, 0.5 t, 0) */
+    Reach r;
+    r.add(c);
+    return r.box();
+}
+
+/* the banded plan with the fewest bytes over n_bands in {1, 2, 4 ... kMaxBands}; false if no band count is addressable */
+bool plan_bands(double t0, double t1, unsigned dust_fam, BandPlan& bp, size_t& band_cells) {
+    const double w_min = 0.2529, w_max = 1.0001;          /* omega = (10/rc)^1.5 for rc in [10, 25]: [0.25298, 1] */
+    bool found = false;
+    for (int nb = 1; nb <= kMaxBands; nb *= 2) {
+        BandPlan cand;
+        memset(&cand, 0, sizeof(cand));
+        cand.n_bands = nb; cand.w_min = (float)w_min; cand.w_scale = (float)(nb / (w_max - w_min));
+        size_t cells = 0;
+        bool ok = true;
+        for (int f = 0; f < rrt::kBandFamilies && ok; ++f) {
+            cand.present[f] = (dust_fam & kFineDustBits[f]) != 0;
+            for (int b = 0; b < nb && ok; ++b) {
+                /* the device picks the band as (int)((omega - w_min) * w_scale) in binary32: 1e-5 of slack on either side */
+                const double wa = (double)cand.w_min + (double)b / (double)cand.w_scale - 1e-5, wb = (double)cand.w_min + (double)(b + 1) / (double)cand.w_scale + 1e-5;
+                LutBox bx = cand.present[f] ? band_box(f, t0, t1, b == 0 ? 0.25 : wa, b == nb - 1 ? 1.0 : wb) : LutBox{0, 0, 0, 2, 2, 2};
+                ok = lut_box_addressable(bx);
+                cand.box[f][b] = bx;
+                cells += (size_t)bx.nx * bx.ny * bx.nz;
+            }
+        }
+        if (ok && (!found || cells < band_cells)) { bp = cand; band_cells = cells; found = true; }
+    }
+    return found;
+}
+
+/* boxes + byte size of a table over [t0, t1] at `coverage` (RRT_TABLE_FULL .. COARSEST, optionally | RRT_TABLE_BANDED or
+ * | RRT_TABLE_DENSE to force a layout); RRT_ERR_INVALID_ARGUMENT for what create would refuse.  Without a forced layout:
+ * dense (one box for all dust families, the layout every window near the origin of the clock gets, no extra loads) unless
+ * that box is unaddressable or larger than kDenseLimitBytes and the banded plan is smaller. */
+constexpr size_t kDenseLimitBytes = (size_t)768 << 20;
+int plan_table(float t0, float t1, int coverage_arg, NoiseTableObject& nt) {
     if (!(t0 <= t1) || !(t0 >= -1.0e4f) || !(t1 <= 1.0e4f)) return RRT_ERR_INVALID_ARGUMENT;
+    const int coverage = coverage_arg & 0xf, forced = coverage_arg & ~0xf;
     if (coverage < RRT_TABLE_FULL || coverage > RRT_TABLE_COARSEST) return RRT_ERR_INVALID_ARGUMENT;
+    if (forced != 0 && forced != RRT_TABLE_BANDED && forced != RRT_TABLE_DENSE) return RRT_ERR_INVALID_ARGUMENT;
     memset(&nt, 0, sizeof(nt));
     nt.t0 = t0; nt.t1 = t1; nt.coverage = coverage; nt.device = -1;
     coverage_families(coverage, nt.acc_families, nt.dust_families);
-    lut_boxes((double)t0, (double)t1, nt.acc_families, nt.dust_families, nt.acc, nt.dust);
-    if (!lut_box_addressable(nt.acc) || !lut_box_addressable(nt.dust)) return RRT_ERR_INVALID_ARGUMENT;
-    nt.bytes = ((size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz + (size_t)nt.dust.nx * nt.dust.ny * nt.dust.nz) * sizeof(float4);
+    /* dense */
+    NoiseTableObject dense = nt;
+    lut_boxes((double)t0, (double)t1, dense.acc_families, dense.dust_families, dense.acc, dense.dust);
+    const bool dense_ok = lut_box_addressable(dense.acc) && lut_box_addressable(dense.dust);
+    dense.bytes = ((size_t)dense.acc.nx * dense.acc.ny * dense.acc.nz + (size_t)dense.dust.nx * dense.dust.ny * dense.dust.nz) * sizeof(float4);
+    /* banded: the coarse dust families keep the one box, the fine ones (if the coverage has any) get a box per band */
+    NoiseTableObject band = nt;
+    bool band_ok = (nt.dust_families & kFineDustMask) != 0 && forced != RRT_TABLE_DENSE;
+    if (band_ok) {
+        LutBox acc_union;
+        lut_boxes((double)t0, (double)t1, band.acc_families, band.dust_families & ~kFineDustMask, acc_union, band.dust);
+        size_t band_cells = 0;
+        band_ok = lut_box_addressable(band.dust) && plan_bands((double)t0, (double)t1, band.dust_families, band.bands, band_cells);
+        if (band_ok) {
+            size_t at = 0;
+            for (int o = 0; o < rrt::kLutAccOctaves; ++o) {          /* octaves the coverage does not serve: a token box, never read */
+                const LutBox bx = ((band.acc_families >> o) & 1u) || o == 0 ? acc_octave_box((double)t0, (double)t1, o) : LutBox{0, 0, 0, 2, 2, 2};
+                band_ok = band_ok && lut_box_addressable(bx);
+                band.bands.acc_box[o] = bx; band.bands.acc_cell0[o] = (unsigned)at;
+                at += (size_t)bx.nx * bx.ny * bx.nz;
+            }
+            band.acc = band.bands.acc_box[0];                          /* what rrt_noise_table_info reports as "the" accretion box */
+            band.bands.dust_cell0 = (unsigned)at;
+            at += (size_t)band.dust.nx * band.dust.ny * band.dust.nz;
+            for (int f = 0; f < rrt::kBandFamilies; ++f)
+                for (int b = 0; b < band.bands.n_bands; ++b) {
+                    band.bands.cell0[f][b] = (unsigned)at;
+                    at += (size_t)band.bands.box[f][b].nx * band.bands.box[f][b].ny * band.bands.box[f][b].nz;
+                }
+            band_ok = at < ((size_t)1 << 32);
+            band.bands.entries_offset = (at * sizeof(float4) + 255) & ~(size_t)255;
+            band.bytes = band.bands.entries_offset + ((size_t)rrt::kBandFamilies * band.bands.n_bands + rrt::kLutAccOctaves) * sizeof(rrt::BandLut);
+            band.banded = true;
+        }
+    }
+    const bool take_band = band_ok && (forced == RRT_TABLE_BANDED || !dense_ok || (dense.bytes > kDenseLimitBytes && band.bytes < dense.bytes));
+    if (forced == RRT_TABLE_BANDED && !band_ok) return RRT_ERR_INVALID_ARGUMENT;
+    if (take_band) { nt = band; return RRT_OK; }
+    if (!dense_ok) return RRT_ERR_INVALID_ARGUMENT;
+    nt = dense;
     return RRT_OK;
+}
+
+/* first cell of the (coarse or only) dust box */
+size_t dust_cell0(const NoiseTableObject& nt) { return nt.banded ? (size_t)nt.bands.dust_cell0 : (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz; }
+
+rrt::DustBands make_bands(const NoiseTableObject& nt) {
+    rrt::DustBands d;
+    d.entries = nt.banded ? reinterpret_cast<const rrt::BandLut*>(reinterpret_cast<const char*>(nt.d_cells) + nt.bands.entries_offset) : nullptr;
+    d.n_bands = nt.banded ? nt.bands.n_bands : 1;
+    d.w_min = nt.bands.w_min; d.w_scale = nt.bands.w_scale;
+    return d;
 }
 
 NoiseLut make_lut(const float4* cells, const LutBox& b, unsigned families) {
@@ -409,7 +540,7 @@ int fill_args(FrameArgs& a, LaunchOpts& o, void* out, int width, int height, flo
         if (!to || !on_current_device(to->device)) return RRT_ERR_BAD_HANDLE;
     }
     o.media = prm.volumetrics != 0 ? 1 : 0;
-    memset(&a.lut_acc, 0, sizeof(a.lut_acc)); memset(&a.lut_dust, 0, sizeof(a.lut_dust));
+    memset(&a.lut_acc, 0, sizeof(a.lut_acc)); memset(&a.lut_dust, 0, sizeof(a.lut_dust)); memset(&a.dust_bands, 0, sizeof(a.dust_bands));
     if (prm.noise_table != 0) {
         NoiseTableObject nt;
         {
@@ -421,9 +552,10 @@ int fill_args(FrameArgs& a, LaunchOpts& o, void* out, int width, int height, flo
         if (!on_current_device(nt.device)) return RRT_ERR_BAD_HANDLE;
         /* the boxes were sized for t0 <= time <= t1; any other time runs the arithmetic kernels (same bytes) */
         if (o.media && time >= nt.t0 && time <= nt.t1) {
-            o.media = 2;
+            o.media = nt.banded ? 3 : 2;
             a.lut_acc = make_lut(nt.d_cells, nt.acc, nt.acc_families);
-            a.lut_dust = make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust, nt.dust_families);
+            a.lut_dust = make_lut(nt.d_cells + dust_cell0(nt), nt.dust, nt.dust_families);
+            a.dust_bands = make_bands(nt);
         }
     }
     o.arith = prm.arith_mode;
@@ -464,7 +596,7 @@ int auto_pool_rounds(const volatile DeferCounters* h, unsigned capacity) {
  * of the pool, on its own stream */
 /* the kernels of one arithmetic mode, instantiated per (spin, tables) */
 template <int ARITH>
-int enqueue_chain_arith(const FrameArgs& a, bool lut, dim3 grid, dim3 block, int rounds, hipStream_t st) {
+int enqueue_chain_arith(const FrameArgs& a, int media, dim3 grid, dim3 block, int rounds, hipStream_t st) {
     const bool spin = a.spin != 0.0f;
     for (int r = 0; r < rounds; ++r) {
         const bool last = r == rounds - 1;
@@ -473,12 +605,13 @@ int enqueue_chain_arith(const FrameArgs& a, bool lut, dim3 grid, dim3 block, int
         if (spin) RRT_MARCH(true); else RRT_MARCH(false);
 #undef RRT_MARCH
         RRT_HIP(hipGetLastError());
-        if (lut) hipLaunchKernelGGL((eval_sample_rows<ARITH, true>), dim3(2048), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((eval_sample_rows<ARITH, false>), dim3(2048), dim3(256), 0, st, a);
+        if (media == 3) hipLaunchKernelGGL((eval_sample_rows<ARITH, 3>), dim3(2048), dim3(256), 0, st, a);
+        else if (media == 2) hipLaunchKernelGGL((eval_sample_rows<ARITH, 2>), dim3(2048), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((eval_sample_rows<ARITH, 1>), dim3(2048), dim3(256), 0, st, a);
         RRT_HIP(hipGetLastError());
 #define RRT_COMP3(S, L) do { if (last) hipLaunchKernelGGL((composite_and_shade<S, ARITH, L, true>), grid, block, 0, st, a); \
                              else hipLaunchKernelGGL((composite_and_shade<S, ARITH, L, false>), grid, block, 0, st, a); } while (0)
-#define RRT_COMP(S) do { if (lut) RRT_COMP3(S, true); else RRT_COMP3(S, false); } while (0)
+#define RRT_COMP(S) do { if (media == 3) RRT_COMP3(S, 3); else if (media == 2) RRT_COMP3(S, 2); else RRT_COMP3(S, 1); } while (0)
         if (spin) RRT_COMP(true); else RRT_COMP(false);
 #undef RRT_COMP
 #undef RRT_COMP3
@@ -491,13 +624,13 @@ int enqueue_chain_arith(const FrameArgs& a, bool lut, dim3 grid, dim3 block, int
 
 /* one chain = march -> evaluate -> composite (in rounds) over dispatch rows [row0, row1) of the launch, in its own slice
  * of the pool, on its own stream */
-int enqueue_chain(FrameArgs a, int arith, bool lut, dim3 full_grid, int row0, int row_stride, int n_rows, int rounds, hipStream_t st) {
+int enqueue_chain(FrameArgs a, int arith, int media, dim3 full_grid, int row0, int row_stride, int n_rows, int rounds, hipStream_t st) {
     if (n_rows <= 0) return RRT_OK;
     const dim3 block(kWGThreads), grid(full_grid.x, (unsigned)n_rows);
     a.grid_rows = (int)full_grid.y; a.grid_row_base = row0; a.grid_row_stride = row_stride;
-    if (arith == kArithFast) return enqueue_chain_arith<kArithFast>(a, lut, grid, block, rounds, st);
-    if (arith == kArithFmad) return enqueue_chain_arith<kArithFmad>(a, lut, grid, block, rounds, st);
-    return enqueue_chain_arith<kArithStrict>(a, lut, grid, block, rounds, st);
+    if (arith == kArithFast) return enqueue_chain_arith<kArithFast>(a, media, grid, block, rounds, st);
+    if (arith == kArithFmad) return enqueue_chain_arith<kArithFmad>(a, media, grid, block, rounds, st);
+    return enqueue_chain_arith<kArithStrict>(a, media, grid, block, rounds, st);
 }
 
 /* Three-pass launch through a workspace.  Returns RRT_OK after enqueuing, or -1 if the workspace cannot
@@ -513,7 +646,7 @@ int enqueue_chain(FrameArgs a, int arith, bool lut, dim3 full_grid, int row0, in
  * other.  Same kernels, same arithmetic, same bytes; an eighth of the bench frame 5.7 -> 5.2 ms, of the view from inside
  * the disk 12.4 -> 9.5 ms (profiles/r04_split_chain_probe.txt).  The side stream and its events belong to the workspace;
  * a launch that is being captured into a graph, or a small one, runs one chain. */
-int launch_deferred(FrameArgs a, int arith, bool lut, const WorkspaceObject& ws, int pool_rounds, int chains_wanted, hipStream_t st) {
+int launch_deferred(FrameArgs a, int arith, int media, const WorkspaceObject& ws, int pool_rounds, int chains_wanted, hipStream_t st) {
     dim3 grid((a.width + kWGPixX - 1) / kWGPixX, (a.rows.n_local_rows + kWGPixY - 1) / kWGPixY);
     const size_t n_waves = (size_t)grid.x * grid.y * kWGWaves;
     const size_t n_lanes = n_waves * 64;
@@ -575,7 +708,7 @@ int launch_deferred(FrameArgs a, int arith, bool lut, const WorkspaceObject& ws,
         b.block_capacity = (unsigned)cap_of[c];
         const int rounds = pool_rounds > 0 ? pool_rounds : auto_pool_rounds(ws.h_stats ? ws.h_stats + c : nullptr, b.block_capacity);
         const hipStream_t cs = c == 1 ? ws.side : st;
-        const int rc = enqueue_chain(b, arith, lut, grid, row_first[c], row_step, row_count[c], rounds, cs);
+        const int rc = enqueue_chain(b, arith, media, grid, row_first[c], row_step, row_count[c], rounds, cs);
         if (rc != RRT_OK) return rc;
         /* what this chain needed, for the next launch's round count and pool split (and rrt_workspace_stats) */
         if (ws.h_stats) RRT_HIP(hipMemcpyAsync(ws.h_stats + c, b.ctr, sizeof(DeferCounters), hipMemcpyDeviceToHost, cs));
@@ -705,7 +838,7 @@ int launch(const FrameArgs& a, const LaunchOpts& o, bool debug, hipStream_t st) 
     }
     bool launched = false;
     if (deferred) {
-        const int rc = launch_deferred(b, o.arith, o.media == 2, ws, o.pool_rounds, o.pass_chains, st);
+        const int rc = launch_deferred(b, o.arith, o.media, ws, o.pool_rounds, o.pass_chains, st);
         if (rc > 0) return rc;
         launched = rc == RRT_OK;
     }
@@ -716,7 +849,7 @@ int launch(const FrameArgs& a, const LaunchOpts& o, bool debug, hipStream_t st) 
 #define RRT_LAUNCH3(S, M, D) do { if (arith == kArithFast) RRT_LAUNCH4(S, M, D, kArithFast); else if (arith == kArithFmad) RRT_LAUNCH4(S, M, D, kArithFmad); \
                                   else RRT_LAUNCH4(S, M, D, kArithStrict); } while (0)
 #define RRT_LAUNCH2(S, M) do { if (debug) RRT_LAUNCH3(S, M, true); else RRT_LAUNCH3(S, M, false); } while (0)
-#define RRT_LAUNCH1(S) do { if (media == 2) RRT_LAUNCH2(S, 2); else if (media == 1) RRT_LAUNCH2(S, 1); else RRT_LAUNCH2(S, 0); } while (0)
+#define RRT_LAUNCH1(S) do { if (media == 3) RRT_LAUNCH2(S, 3); else if (media == 2) RRT_LAUNCH2(S, 2); else if (media == 1) RRT_LAUNCH2(S, 1); else RRT_LAUNCH2(S, 0); } while (0)
         if (spin) RRT_LAUNCH1(true); else RRT_LAUNCH1(false);
 #undef RRT_LAUNCH1
 #undef RRT_LAUNCH2
@@ -1104,10 +1237,35 @@ int rrt_noise_table_create_window(float t0, float t1, int coverage, int* out_id)
     RRT_HIP(hipGetDevice(&nt.device));
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&nt.d_cells), nt.bytes);
     if (e != hipSuccess) { (void)hipGetLastError(); snprintf(g_hip_err, sizeof(g_hip_err), "hipMalloc(noise table, %zu bytes): %s", nt.bytes, hipGetErrorString(e)); return e == hipErrorOutOfMemory ? RRT_ERR_OUT_OF_MEMORY : RRT_ERR_HIP; }
-    hipLaunchKernelGGL(build_noise_table, dim3(4096), dim3(256), 0, nullptr, nt.d_cells, nt.acc);
-    hipLaunchKernelGGL(build_noise_table, dim3(4096), dim3(256), 0, nullptr,
-                       nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust);
+    auto fill_box = [&](const LutBox& bx, size_t cell0) {
+        const size_t n = (size_t)bx.nx * bx.ny * bx.nz;
+        hipLaunchKernelGGL(build_noise_table, dim3((unsigned)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, nullptr, nt.d_cells + cell0, bx);
+    };
+    auto record = [&](const LutBox& bx, unsigned cell0) {
+        const NoiseLut L = make_lut(nullptr, bx, 0u);
+        rrt::BandLut r;
+        memset(&r, 0, sizeof(r));
+        r.cell0 = cell0; r.origin = L.origin; r.nx = L.nx; r.nxy = L.nxy; r.last = L.last;
+        return r;
+    };
+    if (!nt.banded) fill_box(nt.acc, 0);
+    fill_box(nt.dust, dust_cell0(nt));
     e = hipGetLastError();
+    if (e == hipSuccess && nt.banded) {
+        std::vector<rrt::BandLut> recs((size_t)rrt::kBandFamilies * nt.bands.n_bands + rrt::kLutAccOctaves);
+        for (int o = 0; o < rrt::kLutAccOctaves; ++o) {
+            fill_box(nt.bands.acc_box[o], nt.bands.acc_cell0[o]);
+            recs[(size_t)rrt::kBandFamilies * nt.bands.n_bands + o] = record(nt.bands.acc_box[o], nt.bands.acc_cell0[o]);
+        }
+        for (int f = 0; f < rrt::kBandFamilies; ++f)
+            for (int b = 0; b < nt.bands.n_bands; ++b) {
+                fill_box(nt.bands.box[f][b], nt.bands.cell0[f][b]);
+                recs[(size_t)f * nt.bands.n_bands + b] = record(nt.bands.box[f][b], nt.bands.cell0[f][b]);
+            }
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(reinterpret_cast<char*>(nt.d_cells) + nt.bands.entries_offset, recs.data(),
+                                           recs.size() * sizeof(rrt::BandLut), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { (void)hipFree(nt.d_cells); return hip_fail(e, "build_noise_table"); }
     std::lock_guard<std::mutex> lk(g_nt_mu);
@@ -1152,7 +1310,7 @@ int rrt_noise_table_window(int id, float* t0, float* t1, int* coverage, int* dev
     if (it == g_nt.end()) return RRT_ERR_BAD_HANDLE;
     if (t0) *t0 = it->second.t0;
     if (t1) *t1 = it->second.t1;
-    if (coverage) *coverage = it->second.coverage;
+    if (coverage) *coverage = it->second.coverage | (it->second.banded ? RRT_TABLE_BANDED : 0);
     if (device) *device = it->second.device;
     return RRT_OK;
 }
@@ -1165,6 +1323,34 @@ int rrt_noise_table_plan_window(float t0, float t1, int coverage, size_t* bytes,
     if (bytes) *bytes = rc == RRT_OK ? nt.bytes : 0;
     if (rc != RRT_OK) return rc;
     if (boxes12) { memcpy(boxes12, &nt.acc, sizeof(LutBox)); memcpy(boxes12 + 6, &nt.dust, sizeof(LutBox)); }
+    return RRT_OK;
+}
+
+int rrt_noise_table_plan_layout(float t0, float t1, int coverage, int* banded, int* n_bands, float* w_min, float* w_scale,
+                                int32_t* band_boxes, int cap_bands, int32_t* acc_octave_boxes) {
+    if (!banded || !n_bands) return RRT_ERR_INVALID_ARGUMENT;
+    NoiseTableObject nt;
+    const int rc = plan_table(t0, t1, coverage, nt);
+    if (rc != RRT_OK) return rc;
+    *banded = nt.banded ? 1 : 0;
+    *n_bands = nt.banded ? nt.bands.n_bands : 0;
+    if (w_min) *w_min = nt.bands.w_min;
+    if (w_scale) *w_scale = nt.bands.w_scale;
+    if (nt.banded && band_boxes) {
+        if (cap_bands < nt.bands.n_bands) return RRT_ERR_INVALID_ARGUMENT;
+        for (int f = 0; f < rrt::kBandFamilies; ++f)
+            for (int b = 0; b < nt.bands.n_bands; ++b) {
+                const LutBox& bx = nt.bands.box[f][b];
+                const int v[6] = {bx.x0, bx.y0, bx.z0, bx.nx, bx.ny, bx.nz};
+                memcpy(band_boxes + ((size_t)f * cap_bands + b) * 6, v, sizeof(v));
+            }
+    }
+    if (nt.banded && acc_octave_boxes)
+        for (int o = 0; o < rrt::kLutAccOctaves; ++o) {
+            const LutBox& bx = nt.bands.acc_box[o];
+            const int v[6] = {bx.x0, bx.y0, bx.z0, bx.nx, bx.ny, bx.nz};
+            memcpy(acc_octave_boxes + (size_t)o * 6, v, sizeof(v));
+        }
     return RRT_OK;
 }
 

@@ -116,8 +116,10 @@ struct FrameArgs {
     size_t n_lanes;
     uint8_t* sample_blocks;
     unsigned block_capacity;
-    /* lattice-hash tables (rrt_noise_table); only read by the kernels instantiated with MEDIA == 2 */
+    /* lattice-hash tables (rrt_noise_table); only read by the kernels instantiated with MEDIA >= 2; dust_bands only with
+     * MEDIA == 3 (the fine dust families in per-omega-band boxes: rrt_device.h, DustBands) */
     NoiseLut lut_acc, lut_dust;
+    DustBands dust_bands;
     /* cost-ordered dispatch of the single-kernel path (rrt_tile_order): dispatch slot -> wave tile, and where a wave
      * leaves the clocks it took; both NULL: the static centre-out order */
     const unsigned* tile_perm;
@@ -322,7 +324,8 @@ __device__ __forceinline__ void zone_step(bool near_bh, bool in_disk, float& h, 
 constexpr float kVacuumR = kDiskOut + 5.0f;
 
 /* The whole march of one ray with the media sampled in line: raymarcher.cu:41-121.
- * MEDIA: 0 = densities read 0 ("skybox only"), 1 = full media, 2 = full media with the lattice-hash tables.
+ * MEDIA: 0 = densities read 0 ("skybox only"), 1 = full media, 2 = full media with the lattice-hash tables, 3 = with the
+ * tables in their banded layout (rrt_device.h: DustBands).
  * `i`: in = first step (0, or where a resumed ray stopped), out = steps taken.  When every lane starts at the
  * same step the loop counter stays in a scalar register; the per-ray count is written once, at the exit. */
 template <bool SPIN, int MEDIA, bool FAST>
@@ -347,7 +350,7 @@ __device__ __forceinline__ void march_inline_v1(const FrameArgs& a, v3& p, v3& v
 
         if (MEDIA != 0 && (in_disk || in_cloud)) {
             float d_disk, d_cloud;
-            media_densities<MEDIA == 2>(rel_p, a.time, in_disk, in_cloud, a.lut_acc, a.lut_dust, oob, d_disk, d_cloud);
+            media_densities<MEDIA>(rel_p, a.time, in_disk, in_cloud, a.lut_acc, a.lut_dust, a.dust_bands, oob, d_disk, d_cloud);
             accumulate_sample(acc, d_disk, d_cloud, rel_p, r, vel, h, a.spin);
         }
         if (r > 250.0f && dot(rel_p, vel) > 0.0f) { steps = k + 1; break; }
@@ -401,7 +404,7 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
                 integrate_rk4_lean<SPIN, false, FMA>(p, vel, h, hh, h6, a.drag_c, r2, r, y, hy, ys, hs, hcp);
                 if (MEDIA != 0 && (in_disk || in_cloud)) {
                     float d_disk, d_cloud;
-                    media_densities<MEDIA == 2>(rel_p, a.time, in_disk, in_cloud, a.lut_acc, a.lut_dust, oob, d_disk, d_cloud);
+                    media_densities<MEDIA>(rel_p, a.time, in_disk, in_cloud, a.lut_acc, a.lut_dust, a.dust_bands, oob, d_disk, d_cloud);
                     accumulate_sample(acc, d_disk, d_cloud, rel_p, r, vel, h, a.spin);
                 }
             }
@@ -747,7 +750,7 @@ __global__ void pool_next_round(DeferCounters* c, unsigned capacity, int last) {
 }
 
 /* ---- pass 2: densities + emission of every pooled sample row, grid-stride over the pool ---- */
-template <int ARITH, bool LUT>
+template <int ARITH, int MEDIA>
 __global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
     const int lane = threadIdx.x & 63;
     const unsigned n_blk = min(a.ctr->next_block, a.block_capacity);
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
             const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
             const float h = near_bh ? kHNear : (in_disk ? kHDisk : kHVac);
             float d_disk, d_cloud;
-            media_densities<LUT>(rel_p, a.time, in_disk, in_cloud, a.lut_acc, a.lut_dust, nullptr, d_disk, d_cloud);
+            media_densities<MEDIA>(rel_p, a.time, in_disk, in_cloud, a.lut_acc, a.lut_dust, a.dust_bands, nullptr, d_disk, d_cloud);
             has = sample_emission(d_disk, d_cloud, rel_p, r, vel, h, a.spin, ex, ey, ez, s);
         }
         /* Round 5: a sample raymarcher.cu:71 would not take is the identity of the accumulation -- the single kernel skips it,
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
 
 /* ---- pass 3: composite each ray's samples in march order; shade the rays of wavefronts that have reached their end;
  *      LAST (the last round the host enqueued): rays still suspended are finished with the media sampled in line ---- */
-template <bool SPIN, int ARITH, bool LUT, bool LAST>
+template <bool SPIN, int ARITH, int MEDIA, bool LAST>
 __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArgs a) {
     if (a.ctr->rounds_run != 0u && a.ctr->last_overflow == 0u) return;      /* a later round with nothing left: all leave */
     const unsigned long long t_start = a.tile_cost ? __builtin_readcyclecounter() : 0ull;
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(kWGThreads) void composite_and_shade(const FrameArg
         /* the pool ran out under this ray at step `steps` and no round is left: carry on from its saved pre-step state
          * with the media sampled in line -- the samples composited above come first, exactly as in the single kernel */
         p = mk(a.finals[4 * a.n_lanes + li], a.finals[5 * a.n_lanes + li], a.finals[6 * a.n_lanes + li]);
-        march_inline<SPIN, LUT ? 2 : 1, ARITH>(a, p, vel, acc, hit, steps, nullptr);
+        march_inline<SPIN, MEDIA, ARITH>(a, p, vel, acc, hit, steps, nullptr);
     }
     if (hit) acc.t = 0.0f;                                         /* raymarcher.cu:49 */
     shade_and_store<false>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, steps);

@@ -178,7 +178,8 @@ __global__ void k_noise3d_lut(int n, const float* p, NoiseLut L, float* out, uns
     if (i < n) out[i] = noise3d_lut(L, ld3(p, i), counts);
 }
 /* the two density functions exactly as the render kernels call them (early-out, table switches) */
-__global__ void k_media_lut(int n, const float* p, float time, NoiseLut la, NoiseLut ld, float* out_disk, float* out_dust,
+template <int MEDIA>
+__global__ void k_media_lut(int n, const float* p, float time, NoiseLut la, NoiseLut ld, DustBands bands, float* out_disk, float* out_dust,
                             unsigned* counts) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -186,7 +187,7 @@ __global__ void k_media_lut(int n, const float* p, float time, NoiseLut la, Nois
     const float r = length(q);                           /* the zone tests of raymarcher.cu:57-58 gate the calls */
     const bool in_disk = fabsf(q.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
     const bool in_cloud = fabsf(q.y) < kCloudH * 1.5f && r < kCloudOut;
-    media_densities<true>(q, time, in_disk, in_cloud, la, ld, counts, out_disk[i], out_dust[i]);
+    media_densities<MEDIA>(q, time, in_disk, in_cloud, la, ld, bands, counts, out_disk[i], out_dust[i]);
 }
 
 /*
@@ -526,7 +527,7 @@ int rrt_unit_noise3d_lut(int n, const float* p, int table, int which, float* out
     }
     if (!on_current_device(nt.device)) return RRT_ERR_BAD_HANDLE;
     const NoiseLut L = which == 0 ? make_lut(nt.d_cells, nt.acc, nt.acc_families)
-                                  : make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust, nt.dust_families);
+                                  : make_lut(nt.d_cells + dust_cell0(nt), nt.dust, nt.dust_families);
     return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_noise3d_lut, g, b, 0, s, n, p, L, out, d_counts); });
 }
 int rrt_unit_media_lut(int n, const float* p, float time, int table, float* out_disk, float* out_dust, unsigned* d_counts, void* st) {
@@ -541,8 +542,10 @@ int rrt_unit_media_lut(int n, const float* p, float time, int table, float* out_
     if (!on_current_device(nt.device)) return RRT_ERR_BAD_HANDLE;
     if (!(time >= nt.t0 && time <= nt.t1)) return RRT_ERR_INVALID_ARGUMENT;
     const NoiseLut la = make_lut(nt.d_cells, nt.acc, nt.acc_families);
-    const NoiseLut ld = make_lut(nt.d_cells + (size_t)nt.acc.nx * nt.acc.ny * nt.acc.nz, nt.dust, nt.dust_families);
-    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_media_lut, g, b, 0, s, n, p, time, la, ld, out_disk, out_dust, d_counts); });
+    const NoiseLut ld = make_lut(nt.d_cells + dust_cell0(nt), nt.dust, nt.dust_families);
+    const DustBands db = make_bands(nt);
+    if (nt.banded) return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_media_lut<3>, g, b, 0, s, n, p, time, la, ld, db, out_disk, out_dust, d_counts); });
+    return unit_launch(n, st, [&](dim3 g, dim3 b, hipStream_t s) { hipLaunchKernelGGL(k_media_lut<2>, g, b, 0, s, n, p, time, la, ld, db, out_disk, out_dust, d_counts); });
 }
 
 int rrt_selfcheck_div_const(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* d_counters, void* st) {

@@ -36,10 +36,10 @@ class HookSky:
 class HookNoiseTable:
     """A noise table in the test library's registry (see HookSky)."""
 
-    def __init__(self, t_max):
+    def __init__(self, t_max, t0=0.0, coverage=0):
         from relativisticraytracer_amd import _lib
         i = C.c_int(0)
-        _lib.check(_lib.load_test().rrt_noise_table_create(float(t_max), C.byref(i)), "rrt_noise_table_create")
+        _lib.check(_lib.load_test().rrt_noise_table_create_window(float(t0), float(t_max), int(coverage), C.byref(i)), "rrt_noise_table_create_window")
         self.id = i.value
 
     def info(self):

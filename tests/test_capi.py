@@ -127,10 +127,88 @@ def test_noise_table_plan_covers_the_reachable_lattice():
 @pytest.mark.parametrize("t0,t1,coverage", [(495.0, 505.0, 1), (495.0, 505.0, 2), (120.0, 150.0, 0), (-20.0, -5.0, 0),
                                             (-3.0, 4.0, 1), (2000.0, 2010.0, 2)])
 def test_noise_table_windows_cover_the_reachable_lattice(t0, t1, coverage):
-    """Sliding windows far along the reference's unbounded simTime (main.cpp:515), negative times, every coverage."""
+    """Sliding windows far along the reference's unbounded simTime (main.cpp:515), negative times, every coverage -- in the
+    DENSE layout (one box per table; forced: far along the clock the automatic choice is the banded one, below)."""
     import relativisticraytracer_amd as rrt
-    plan = rrt.NoiseTable.plan(t1, t0, coverage)
+    plan = rrt.NoiseTable.plan(t1, t0, coverage | rrt.TABLE_DENSE)
     _reachable_cells_inside(plan, t0, t1, coverage, 11)
+
+
+@pytest.mark.parametrize("t0,t1,coverage", [(495.0, 505.0, 0), (495.0, 505.0, 1), (995.0, 1005.0, 1), (0.0, 32.0, 0), (-40.0, -30.0, 0),
+                                            (95.0, 105.0, 0)])
+def test_banded_noise_tables_cover_the_reachable_lattice(t0, t1, coverage):
+    """Round 5: the BANDED layout -- the fine dust families (ridge octaves 1 and 2, the detail octave) in
+    one box per band of omega = (10/rc)^1.5, the accretion table in one box per octave.  Host arithmetic only: for random
+    in-zone points and times of the window, re-derived in float64 from densities.h, every lattice cell a table-served call
+    touches lies inside the box of ITS band (picked by the device's own rule, evaluated in float32 as the device does) /
+    octave; the coarse dust families inside the one dense box that is left; and the whole table is much smaller than dense."""
+    import numpy as np
+    import relativisticraytracer_amd as rrt
+    plan = rrt.NoiseTable.plan(t1, t0, coverage | rrt.TABLE_BANDED)
+    lay = rrt.NoiseTable.plan_layout(t1, t0, coverage | rrt.TABLE_BANDED)
+    assert lay["banded"] and lay["n_bands"] in (1, 2, 4, 8, 16, 32, 64)
+    rng = np.random.default_rng(5)
+    n = 300000
+    rc = rng.uniform(10.0, 25.0, n); ang = rng.uniform(-np.pi, np.pi, n); t = rng.uniform(t0, t1, n)
+    t[:4] = (t0, t1, t0, t1); rc[:4] = (10.0, 10.0, 25.0, 25.0)
+    rc[4:4 + 2 * lay["n_bands"]] = np.repeat(10.0 / np.maximum((lay["w_min"] + np.arange(lay["n_bands"]) / lay["w_scale"]), 0.2530) ** (2 / 3), 2).clip(10, 25)   # band edges
+    # the device's band rule, in float32
+    q = (np.float32(10.0) / rc.astype(np.float32)).astype(np.float32)
+    omega32 = (q * np.sqrt(q).astype(np.float32)).astype(np.float32)
+    band = np.clip(((omega32 - np.float32(lay["w_min"])) * np.float32(lay["w_scale"])).astype(np.int32), 0, lay["n_bands"] - 1)
+    omega = (10.0 / rc) ** 1.5
+    y = rng.uniform(-0.75, 0.75, n)
+    sc = np.stack([rc * 0.8, y * 15, (ang - t * omega) * 10], 1)
+    w = rng.uniform(-0.76, 0.76, (n, 3))
+    fc = sc + 1.5 * w
+    fams = {0: fc * 2.1, 1: fc * 2.1 ** 2, 2: fc * 4 + np.stack([np.zeros(n), 0.5 * t, np.zeros(n)], 1)}
+    served = {0: (0, 1, 2), 1: (0,), 2: ()}[coverage]
+    for f in served:
+        cell = np.floor(fams[f]).astype(np.int64)
+        box = lay["band_boxes"][f][band]                       # (n, 6)
+        for k in range(3):
+            assert (cell[:, k] >= box[:, k]).all() and (cell[:, k] + 1 <= box[:, k] + box[:, 3 + k] - 1).all(), (f, k)
+    # accretion octaves
+    ya = rng.uniform(-4, 4, n)
+    rot = ang - t * 3.5 * omega
+    c = np.stack([rc * np.cos(rot) * 0.45, ya * 4 * 0.45 + 0.35 * t, rc * np.sin(rot) * 0.45], 1)
+    for o in range(3 if coverage == 2 else 4):
+        cell = np.floor(c); bx = lay["acc_octave_boxes"][o]
+        for k in range(3):
+            assert cell[:, k].min() >= bx[k] and cell[:, k].max() + 1 <= bx[k] + bx[3 + k] - 1, (o, k)
+        c = c * 2.05 + 10
+    # the coarse dust families: the dense box that is left
+    dx0, dy0, dz0, dnx, dny, dnz = plan["dust_box"]
+    pts = []
+    for f in [sc * 0.15 + np.array(o) for o in ((0, 0, 0), (1, 2, 3), (4, 5, 6))] + [(sc + 3 * w) * 0.4 + np.array(o) for o in ((0, 0, 0), (2, 1, 0), (0, 3, 1))]:
+        pts += [f, f * 2.05 + 10]
+    pts += [fc]
+    for c in pts:
+        cell = np.floor(c)
+        for k, (o, m) in enumerate(((dx0, dnx), (dy0, dny), (dz0, dnz))):
+            assert cell[:, k].min() >= o and cell[:, k].max() + 1 <= o + m - 1
+    if t0 >= 400.0:
+        try:
+            dense = rrt.NoiseTable.plan(t1, t0, coverage | rrt.TABLE_DENSE)["bytes"]
+        except rrt.RRTError:
+            dense = None                                                         # not even addressable
+        assert dense is None or plan["bytes"] < 0.5 * dense
+
+
+def test_ten_seconds_at_t_500_fit_two_gib_at_full_coverage():
+    """VERDICT r04 next #4, the done criterion: rrt_noise_table_fit_window(495, 505, 2 GiB) returns RRT_TABLE_FULL (rounds 3-4:
+    unaddressable at full coverage, COARSE in 1.35 GB).  And the windows of the bench / of BASELINE config 5 keep the dense
+    layout they always had."""
+    import relativisticraytracer_amd as rrt
+    t1, cov, nbytes = rrt.NoiseTable.fit(495.0, 505.0, 2 << 30)
+    assert (t1, cov) == (505.0, rrt.TABLE_FULL) and 0 < nbytes <= 2 << 30
+    assert rrt.NoiseTable.plan_layout(505.0, 495.0, rrt.TABLE_FULL)["banded"]
+    assert not rrt.NoiseTable.plan_layout(32.0, 0.0, rrt.TABLE_FULL)["banded"] and not rrt.NoiseTable.plan_layout(13.5, 0.0)["banded"]
+    assert rrt.NoiseTable.plan(32.0)["bytes"] == 493455872                      # the bench's table: unchanged since round 3
+    with pytest.raises(rrt.RRTError):
+        rrt.NoiseTable.plan(505.0, 495.0, rrt.TABLE_COARSEST | rrt.TABLE_BANDED)   # nothing to band at the coarsest coverage
+    with pytest.raises(rrt.RRTError):
+        rrt.NoiseTable.plan(505.0, 495.0, rrt.TABLE_FULL | rrt.TABLE_BANDED | rrt.TABLE_DENSE)
 
 
 def test_noise_table_plan_refuses_what_create_would_and_fit_stays_in_budget():
@@ -139,10 +217,11 @@ def test_noise_table_plan_refuses_what_create_would_and_fit_stays_in_budget():
     (rrt_noise_table_fit_window) returns the longest window / richest coverage within a byte budget."""
     import relativisticraytracer_amd as rrt
     with pytest.raises(rrt.RRTError):
-        rrt.NoiseTable.plan(600.0)                              # dust box >= 2^28 lattice points at full coverage
+        rrt.NoiseTable.plan(600.0, 0.0, rrt.TABLE_FULL | rrt.TABLE_DENSE)     # dust box >= 2^28 lattice points at full coverage, dense
+    assert rrt.NoiseTable.plan(600.0)["bytes"] > 4 << 30                      # (the banded layout can address it: 5 GB)
     with pytest.raises(rrt.RRTError):
-        rrt.NoiseTable.plan(505.0, 495.0, rrt.TABLE_FULL)       # differential rotation: a window does not bound it
-    assert rrt.NoiseTable.plan(505.0, 495.0, rrt.TABLE_COARSE)["bytes"] < 2 << 30
+        rrt.NoiseTable.plan(505.0, 495.0, rrt.TABLE_FULL | rrt.TABLE_DENSE)     # differential rotation: a window does not bound the one dense box
+    assert rrt.NoiseTable.plan(505.0, 495.0, rrt.TABLE_COARSE | rrt.TABLE_DENSE)["bytes"] < 2 << 30
     with pytest.raises(rrt.RRTError):
         rrt.NoiseTable.plan(1.0, 2.0)                           # t0 > t1
     # coarser coverage, smaller table; longer window, larger table
@@ -153,14 +232,16 @@ def test_noise_table_plan_refuses_what_create_would_and_fit_stays_in_budget():
     # a 12.5 s sequence (BASELINE config 5): one table, full coverage, whole sequence
     t1, cov, nbytes = rrt.NoiseTable.fit(0.0, 13.5, budget)
     assert (t1, cov) == (13.5, rrt.TABLE_FULL) and 0 < nbytes <= budget
-    # a ten-minute sequence: a shorter window first, then coarser tables, always inside the budget
-    t, n_windows, coarsest = 0.0, 0, 0
-    while t < 600.0 and n_windows < 200:
-        t1, cov, nbytes = rrt.NoiseTable.fit(t, 600.0, budget)
-        assert nbytes > 0 and nbytes <= budget and t1 > t
-        assert rrt.NoiseTable.plan(t1, t, cov)["bytes"] == nbytes
-        t, n_windows, coarsest = t1 + 1.0 / 24.0, n_windows + 1, max(coarsest, cov)
-    assert t >= 600.0 and 2 <= n_windows < 100 and coarsest >= rrt.TABLE_COARSE
+    # a ten-minute sequence: shorter windows as the clock runs, always inside the budget -- and, since the banded layout
+    # (round 5), at FULL coverage all the way (rounds 3-4 fell to COARSE after a few minutes); past ~15 minutes it gets coarser
+    for t_end, want_coarsest in ((600.0, rrt.TABLE_FULL), (1200.0, rrt.TABLE_COARSE)):
+        t, n_windows, coarsest = t_end - 600.0, 0, 0
+        while t < t_end and n_windows < 400:
+            t1, cov, nbytes = rrt.NoiseTable.fit(t, t_end, budget)
+            assert nbytes > 0 and nbytes <= budget and t1 > t
+            assert rrt.NoiseTable.plan(t1, t, cov)["bytes"] == nbytes
+            t, n_windows, coarsest = t1 + 1.0 / 24.0, n_windows + 1, max(coarsest, cov)
+        assert t >= t_end and 2 <= n_windows < 300 and coarsest == want_coarsest, (t_end, n_windows, coarsest)
     # nothing fits: bytes == 0, and the caller renders without a table
     assert rrt.NoiseTable.fit(5000.0, 5100.0, 64 << 20)[2] == 0
 

@@ -1009,23 +1009,32 @@ def test_config3_all_eight_shards_at_4k_assemble_to_the_single_launch(ctx, po, s
 
 
 def test_noise_table_windows_far_along_the_clock(ctx):
-    """the reference's simTime runs without bound (main.cpp:515).  A frame at t = 500 s through a
-    [495, 505] window (coarse coverage: at full coverage the differential rotation of the dust coordinates makes
-    that box unaddressable, see rrt.h) equals the arithmetic frame, no table read is ever clamped, a time outside
-    the window falls back to the arithmetic kernels, every coverage gives the same bytes, and the drivers' policy
-    object walks a clock across several windows inside its budget."""
+    """the reference's simTime runs without bound (main.cpp:515).  A frame at t = 500 s through
+    a [495, 505] window equals the arithmetic frame, no table read is ever clamped, a time outside the window falls back to
+    the arithmetic kernels, every coverage and both LAYOUTS give the same bytes -- dense (one box per table: unaddressable
+    at full coverage that far along the clock, the differential rotation of the dust coordinates, see rrt.h) and, round 5,
+    banded (the fine dust families in a box per omega band, the accretion table in a box per octave: full coverage at
+    t = 500 s in under 2 GiB) -- and the drivers' policy object walks a clock across several windows inside its budget."""
     import torch
     g, rrt, tex = ctx
     views = [(960, 540, (4.2, 0.6, 4.2), -90.0, -5.7), (640, 360, (35.0, 0.8, 10.0), -106.0, -1.2), (480, 270, (0.0, 10.0, -60.0), 0.0, -10.0)]
     fx = rrt.CameraEffects()
     with pytest.raises(rrt.RRTError):
-        rrt.NoiseTable.window(495.0, 505.0, rrt.TABLE_FULL)
-    for t0, t1, cov, t in ((495.0, 505.0, rrt.TABLE_COARSE, 500.0), (495.0, 505.0, rrt.TABLE_COARSEST, 503.25),
-                           (10.0, 20.0, rrt.TABLE_FULL, 14.0), (10.0, 20.0, rrt.TABLE_COARSE, 14.0), (-8.0, -2.0, rrt.TABLE_FULL, -5.5)):
+        rrt.NoiseTable.window(495.0, 505.0, rrt.TABLE_FULL | rrt.TABLE_DENSE)
+    B, D = rrt.TABLE_BANDED, rrt.TABLE_DENSE
+    for t0, t1, cov, t in ((495.0, 505.0, rrt.TABLE_FULL, 500.0), (495.0, 505.0, rrt.TABLE_FULL, 495.0), (495.0, 505.0, rrt.TABLE_FULL, 505.0),
+                           (495.0, 505.0, rrt.TABLE_COARSE | D, 500.0), (495.0, 505.0, rrt.TABLE_COARSE | B, 500.0),
+                           (495.0, 505.0, rrt.TABLE_COARSEST, 503.25),
+                           (10.0, 20.0, rrt.TABLE_FULL, 14.0), (10.0, 20.0, rrt.TABLE_FULL | B, 14.0), (10.0, 20.0, rrt.TABLE_COARSE, 14.0),
+                           (-8.0, -2.0, rrt.TABLE_FULL, -5.5), (-8.0, -2.0, rrt.TABLE_FULL | B, -5.5)):
         nt = rrt.NoiseTable.window(t0, t1, cov)
         try:
             info = nt.info()
-            assert (info["t0"], info["t1"], info["coverage"]) == (t0, t1, cov) and info["bytes"] == rrt.NoiseTable.plan(t1, t0, cov)["bytes"]
+            want_banded = bool(cov & B) or (t0 > 400.0 and (cov & 0xf) == rrt.TABLE_FULL)
+            assert (info["t0"], info["t1"], info["coverage"] & 0xf) == (t0, t1, cov & 0xf) and info["bytes"] == rrt.NoiseTable.plan(t1, t0, cov)["bytes"]
+            assert bool(info["coverage"] & B) == want_banded, (t0, t1, cov, info["coverage"])
+            if t0 > 400.0 and (cov & 0xf) == rrt.TABLE_FULL:
+                assert info["bytes"] <= 2 << 30
             for (w, h, pos, yaw, pitch) in views:
                 cam = rrt.CameraState.from_angles(pos, yaw, pitch)
                 ref = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda"); out = torch.zeros_like(ref)
@@ -1037,6 +1046,13 @@ def test_noise_table_windows_far_along_the_clock(ctx):
                 rrt.launch_raymarch_debug(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id), lut_oob=oob)
                 torch.cuda.synchronize()
                 assert torch.equal(out, ref) and int(oob.item()) == 0, (t0, t1, cov, t, pos)
+                if want_banded and w == 640:             # ... and through the three-pass path (its own instantiations of the banded code)
+                    ws = rrt.Workspace(96 << 20)
+                    out.zero_()
+                    rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=ws.id, path_policy=2, pool_rounds=8))
+                    torch.cuda.synchronize()
+                    ws.destroy()
+                    assert torch.equal(out, ref), ("three-pass", t0, t1, cov, t)
             # just outside the window: the arithmetic kernels, same bytes
             w, h, pos, yaw, pitch = views[1]
             cam = rrt.CameraState.from_angles(pos, yaw, pitch)

@@ -254,14 +254,16 @@ def test_noise_table_reads_equal_the_arithmetic_hash(g):
         nt.destroy()
 
 
-@pytest.mark.parametrize("t", (0.0, 1.0, 7.5))
-def test_density_functions_with_table_switches_equal_the_arithmetic_ones(g, po, t):
+@pytest.mark.parametrize("t,window", [(0.0, (0.0, 8.0, 0)), (1.0, (0.0, 8.0, 0)), (7.5, (0.0, 8.0, 0)),
+                                      (7.5, (0.0, 8.0, 16)), (500.0, (495.0, 505.0, 0)), (1003.0, (995.0, 1005.0, 1)), (-33.0, (-40.0, -30.0, 16))])
+def test_density_functions_with_table_switches_equal_the_arithmetic_ones(g, po, t, window):
     """The densities exactly as the render kernels evaluate them (early-out + wave-uniform table switches) on
     wave-coherent sample points -- 64 neighbours a few hundredths of a unit apart, as the 8x8-pixel wavefronts
-    of a 4K frame produce -- so that the switches really are on; bits must equal the oracle's."""
+    of a 4K frame produce -- so that the switches really are on; bits must equal the oracle's.  Round 5: also through the
+    BANDED table layout (coverage | 16, or chosen automatically far along the clock: [495, 505 s] at full coverage)."""
     import torch
     import relativisticraytracer_amd as rrt
-    nt = g.HookNoiseTable(8.0)
+    nt = g.HookNoiseTable(window[1], window[0], window[2])
     try:
         rng = np.random.default_rng(29)
         waves = 4096
