@@ -367,11 +367,16 @@ int main(int argc, char** argv) {
         const bool in_window = sim_t >= win_t0 && sim_t <= win_t1;
         if (use_table && !in_window) {
             float t1 = sim_t; int cov = RRT_TABLE_FULL; size_t bytes = 0;
+            // trace points around the rebuild: it synchronises every device and creates a table on each, which on a
+            // starved box takes time that must neither count against --frame-timeout under the name of the last frame nor
+            // leave the watchdog's notices pointing at the wrong phase
+            trace("noise table window: fitting", k);
             rrt_noise_table_fit_window(sim_t, seq_end > sim_t ? seq_end : sim_t, table_budget, &t1, &cov, &bytes);
             bool ok = bytes != 0;
             for (int d = 0; d < gpus; ++d) {
                 Device& D = dev[d];
                 HIPCHK(hipSetDevice(d));
+                trace("noise table window: draining and rebuilding on device", d);
                 HIPCHK(hipDeviceSynchronize());
                 if (D.noise_table) { rrt_noise_table_destroy(D.noise_table); D.noise_table = 0; }
                 if (ok && (rc = rrt_noise_table_create_window(sim_t, t1, cov, &D.noise_table)) != RRT_OK) {
@@ -389,6 +394,7 @@ int main(int argc, char** argv) {
                 if (bytes == 0) t1 = sim_t + 5.0f;          // nothing fits: look again after 5 s of sim time
             }
             win_t0 = sim_t; win_t1 = t1; win_has_table = ok;
+            trace("noise table window: done", k);
             if (ok) { ++table_builds; if (cov > coarsest) coarsest = cov; if (bytes > table_peak) table_peak = bytes; }
         }
         if (use_table && win_has_table) ++table_frames; else ++arith_frames;

@@ -1506,6 +1506,7 @@ int rrt_tile_map_destroy(int id) {
         auto it = g_tm.find(id);
         if (it == g_tm.end()) return RRT_ERR_BAD_HANDLE;
         m = it->second;
+        if (!on_current_device(m->device)) return RRT_ERR_BAD_HANDLE;      /* like every other handle: freed under the device that owns it */
         g_tm.erase(it);
     }
     hipError_t e = hipFree(m->d_img);

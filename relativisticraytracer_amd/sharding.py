@@ -227,6 +227,21 @@ class FrameSharder:
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
                 return bool(flag.item())
 
+            # An explicit tile -> rank map must be THE SAME map on every rank: each rank derives it on its own (rrt_probe_tile_costs
+            # runs in fast arithmetic on that rank's GPU, rrt_tile_map_balance on its host), and a map that differs in one tile
+            # loses or duplicates that tile in the gathered frame without any error.  All ranks compare a digest.
+            if shard_of_tile is not None and world > 1:
+                import hashlib
+                import numpy as np
+                digest = hashlib.sha256(np.asarray(shard_of_tile, dtype=np.int64).tobytes()).digest()[:8]
+                mine = torch.tensor(list(digest), dtype=torch.int32, device=probe.device)
+                lo, hi = mine.clone(), mine.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+                if not bool(torch.equal(lo, hi)):
+                    raise RuntimeError(f"FrameSharder: rank {rank}'s tile -> rank map differs from another rank's "
+                                       "(every rank must be given the same shard_of_tile)")
+
             def try_collective(allgather, asyn):
                 try:
                     if allgather:

@@ -181,6 +181,38 @@ def test_gather_world2_gloo_matches_single_render(pipeline, tile_map):
     assert ok
 
 
+def _worker_maps_differ(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tile_map = [0, 1, 0, 0, 1, 0, 0] if rank == 0 else [0, 1, 0, 1, 1, 0, 0]        # tile 3: both ranks think the other / they own it
+    try:
+        sh.FrameSharder(48, 27, 4, rank, world, "cpu", lambda buf, slot: None, lambda frame, buf, shard: None, shard_of_tile=tile_map)
+        q.put((rank, "accepted"))
+    except RuntimeError as e:
+        q.put((rank, "refused" if "differs from another rank" in str(e) else f"other: {e}"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_with_different_tile_maps_are_refused_world2_gloo():
+    """every rank derives the explicit tile -> rank map by itself (probe + balance); maps that differ in one tile
+    would lose or duplicate that tile in the gathered frame silently.  The sharder compares a digest over all ranks."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_maps_differ, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == {0: "refused", 1: "refused"}, got
+
+
 def test_pipelined_step_single_process_gloo():
     """The collective path on a one-rank gloo group (no subprocesses): frame order and flush()."""
     import torch

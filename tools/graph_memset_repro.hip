@@ -1,0 +1,49 @@
+// dev tool (GPU): does a hipMemsetAsync captured into a hipGraph clear its buffer on EVERY replay?
+//
+// Round 4 replaced the hipMemsetAsync of the three-pass workspace header by a kernel (zero_words) after a captured launch had
+// replayed with stale counters; ADVICE r04 asked for the memset node to be isolated from everything else that round's capture
+// path contained.  This is that case and nothing else: capture { memset(buf, 0, bytes); kernel: out[i] = buf[i]; buf[i] += 7 },
+// replay it `reps` times, and count the words of `out` that are not 0 after each replay -- for the sizes and alignments the
+// workspace header takes (256 B of counters + 16 B per wavefront, rounded to 256).  A correct memset node gives 0 everywhere.
+//   hipcc --offload-arch=gfx950 -O2 tools/graph_memset_repro.hip -o tools/graph_memset_repro && tools/graph_memset_repro
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
+__global__ void read_then_dirty(unsigned* buf, unsigned* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { out[i] = buf[i]; buf[i] += 7u; }
+}
+int main() {
+    const size_t sizes[] = {256, 4096, 256 + 16 * 1000, 256 + 16 * 16200, 256 + 16 * 129600, (size_t)8 << 20};
+    const size_t offsets[] = {0, 256, 4096 + 256};
+    int bad_total = 0;
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    for (size_t bytes0 : sizes) for (size_t off : offsets) {
+        const size_t bytes = (bytes0 + 255) & ~(size_t)255, n = bytes / 4;
+        unsigned *base, *out;
+        CK(hipMalloc(&base, bytes + 8192)); CK(hipMalloc(&out, bytes));
+        unsigned* buf = base + off / 4;
+        CK(hipMemset(base, 0xAB, bytes + 8192));
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        CK(hipMemsetAsync(buf, 0, bytes, st));
+        hipLaunchKernelGGL(read_then_dirty, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, buf, out, n);
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        std::vector<unsigned> h(n);
+        for (int rep = 0; rep < 4; ++rep) {
+            CK(hipGraphLaunch(ge, st));
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(h.data(), out, bytes, hipMemcpyDeviceToHost));
+            size_t bad = 0, first = n;
+            for (size_t i = 0; i < n; ++i) if (h[i] != 0u) { if (first == n) first = i; ++bad; }
+            printf("bytes %9zu offset %5zu replay %d: %zu of %zu words not cleared%s", bytes, off, rep, bad, n, bad ? "" : "\n");
+            if (bad) { printf("  (first at word %zu = 0x%08x)\n", first, h[first]); ++bad_total; }
+        }
+        CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); CK(hipFree(base)); CK(hipFree(out));
+    }
+    printf("%s\n", bad_total ? "MEMSET NODE DEFECT REPRODUCED" : "memset nodes cleared their buffers on every replay: not reproduced in isolation");
+    return 0;
+}
