@@ -579,21 +579,24 @@ constexpr int kMaxPoolRounds = 64;
 /* How many rounds to enqueue (rrt_params.pool_rounds == 0).  The host cannot ask the device without stalling the
  * stream, so it reads the statistics the workspace's PREVIOUS launch left in pinned host memory (an asynchronous copy
  * behind its last kernel; possibly a frame stale, which is all an animation needs): as many rounds as that launch had
- * work for PLUS ONE spare (a view that changes finds room; an idle round costs three near-empty launches, ~20 us: every
- * wave leaves on one scalar load), twice as many plus one if rays were still suspended at its end.  Rays the enqueued
+ * work for -- PLUS ONE spare unless its fullest round left a fifth of the pool free (a view that changes finds room; an idle
+ * round costs four near-empty launches: every wave leaves on one scalar load) --, twice as many plus one if rays were still
+ * suspended at its end.  Rays the enqueued
  * rounds do not finish take the in-line route: the bytes never depend on the guess. */
 int auto_pool_rounds(const volatile DeferCounters* h, unsigned capacity) {
     if (!h) return 2;
     const unsigned run = h->rounds_run, work = h->rounds_with_work, left = h->suspended_left, peak = h->peak_blocks;
     if (run == 0u) return 2;                                    /* no history */
-    (void)peak; (void)capacity;
     int r = (int)(work > 0u ? work : 1u);
+    /* round 5: no spare round while the pool has room to spare -- the previous launch finished everything and its fullest
+     * round used at most 80 % of this launch's pool: a view that changes from one frame to the next does not outgrow that, and
+     * the idle round's four near-empty launches are ~1 % of a rank's share of a frame.  (If it ever does overflow, those rays
+     * finish in line -- same bytes -- and the next launch sees suspended_left != 0.) */
+    if (left == 0u && (unsigned long long)peak * 5ull <= (unsigned long long)capacity * 4ull) return r > kMaxPoolRounds ? kMaxPoolRounds : r;
     r = left != 0u ? 2 * r + 1 : r + 1;
     return r > kMaxPoolRounds ? kMaxPoolRounds : r;
 }
 
-/* one chain = march -> evaluate -> composite (in rounds) over dispatch rows [row0, row1) of the launch, in its own slice
- * of the pool, on its own stream */
 /* the kernels of one arithmetic mode, instantiated per (spin, tables) */
 template <int ARITH>
 int enqueue_chain_arith(const FrameArgs& a, int media, dim3 grid, dim3 block, int rounds, hipStream_t st) {
@@ -668,9 +671,13 @@ int launch_deferred(FrameArgs a, int arith, int media, const WorkspaceObject& ws
         if (st != nullptr && hipStreamIsCapturing(st, &capst) != hipSuccess) { (void)hipGetLastError(); capst = hipStreamCaptureStatusNone; }
         if (capst == hipStreamCaptureStatusNone) chains = 2;
     }
+#ifdef RRT_WS_MEMSET      /* dev builds only: rounds 1-3's hipMemsetAsync, to re-examine round 4's capture failure (LABNOTES.md, round 5) */
+    RRT_HIP(hipMemsetAsync(ws.d_base, 0, off_fin, st));
+#else
     hipLaunchKernelGGL(zero_words, dim3((unsigned)((off_fin / 16 + 255) / 256)), dim3(256), 0, st,
                        reinterpret_cast<uint4*>(ws.d_base), off_fin / 16);        /* counters + wave headers (off_fin is a multiple of 256) */
     RRT_HIP(hipGetLastError());
+#endif
     /* the pool's split: by what each chain pooled last time (the heavy half holds most of the media), 65 : 35 without history */
     size_t cap_of[kMaxChains] = {cap, 0};
     /* which dispatch rows a chain takes: the first and the second half of the static order (the frame's middle and the rest) --

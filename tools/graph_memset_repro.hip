@@ -20,6 +20,11 @@ int main() {
     int bad_total = 0;
     hipStream_t st;
     CK(hipStreamCreate(&st));
+    unsigned* h_pinned;
+    CK(hipHostMalloc(&h_pinned, 4096));
+    // variant 0: memset + kernel, thread-local capture.  variant 1 (closer to the library's captured three-pass launch): global
+    // capture mode, a device-to-pinned-host copy node of the first 64 bytes behind the kernel, a second kernel behind that.
+    for (int variant = 0; variant < 2; ++variant)
     for (size_t bytes0 : sizes) for (size_t off : offsets) {
         const size_t bytes = (bytes0 + 255) & ~(size_t)255, n = bytes / 4;
         unsigned *base, *out;
@@ -27,9 +32,16 @@ int main() {
         unsigned* buf = base + off / 4;
         CK(hipMemset(base, 0xAB, bytes + 8192));
         hipGraph_t g; hipGraphExec_t ge;
-        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        // the buffer is used LIVE first, as the library's workspace is (it holds a finished launch's counters and headers)
+        hipLaunchKernelGGL(read_then_dirty, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, buf, out, n);
+        CK(hipStreamSynchronize(st));
+        CK(hipStreamBeginCapture(st, variant ? hipStreamCaptureModeGlobal : hipStreamCaptureModeThreadLocal));
         CK(hipMemsetAsync(buf, 0, bytes, st));
         hipLaunchKernelGGL(read_then_dirty, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, buf, out, n);
+        if (variant) {
+            CK(hipMemcpyAsync(h_pinned, buf, 64, hipMemcpyDeviceToHost, st));
+            hipLaunchKernelGGL(read_then_dirty, dim3(1), dim3(64), 0, st, buf, out + 0, (size_t)0);     // (touches nothing: a node behind the copy)
+        }
         CK(hipStreamEndCapture(st, &g));
         CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         std::vector<unsigned> h(n);
@@ -39,7 +51,7 @@ int main() {
             CK(hipMemcpy(h.data(), out, bytes, hipMemcpyDeviceToHost));
             size_t bad = 0, first = n;
             for (size_t i = 0; i < n; ++i) if (h[i] != 0u) { if (first == n) first = i; ++bad; }
-            printf("bytes %9zu offset %5zu replay %d: %zu of %zu words not cleared%s", bytes, off, rep, bad, n, bad ? "" : "\n");
+            printf("variant %d bytes %9zu offset %5zu replay %d: %zu of %zu words not cleared%s", variant, bytes, off, rep, bad, n, bad ? "" : "\n");
             if (bad) { printf("  (first at word %zu = 0x%08x)\n", first, h[first]); ++bad_total; }
         }
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); CK(hipFree(base)); CK(hipFree(out));

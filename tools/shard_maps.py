@@ -4,7 +4,7 @@ frame would take on N GPUs (gather / assemble excluded).  Compares tile -> shard
   t mod N         tile t -> shard t mod N (rounds 1-3), with one chain (round 3's path) and with two (round 4)
   probe           rrt_probe_tile_costs + rrt_tile_map_balance (what a first frame can know)
   measured        the tiles' MEASURED costs (rrt_tile_order clocks of the one-chain run, summed per row tile), dealt the same way
-    python tools/shard_maps.py [view] [N] [pool MiB] [spin]      -> profiles/r04_shard_kernel_times_<view>.txt"""
+    python tools/shard_maps.py [view] [N] [pool MiB] [spin]      -> profiles/r0N_shard_kernel_times_<view>.txt"""
 import os, sys
 import numpy as np
 import torch
@@ -36,7 +36,12 @@ def timed(fn, reps=3):
     return best
 
 full = timed(lambda: rrt.launch_raymarch(buf, W, H, t, cam, tex, fx, rrt.RenderParams(spin=spin, noise_table=nt.id)))
-print(f"# {view} 4K a={spin:g}, {N} shards of {R}-row tiles, three-pass through a {pool_mib} MiB pool, noise tables; single-GPU frame (single kernel) {full:.3f} ms")
+_o = rrt.TileOrder()
+full_ord = timed(lambda: rrt.launch_raymarch(buf, W, H, t, cam, tex, fx, rrt.RenderParams(spin=spin, noise_table=nt.id, tile_order=_o.id)), reps=4)
+_o.destroy()
+best_single = min(full, full_ord)
+print(f"# {view} 4K a={spin:g}, {N} shards of {R}-row tiles, three-pass through a {pool_mib} MiB pool, noise tables; single-GPU frame (single kernel) "
+      f"{full:.3f} ms static order, {full_ord:.3f} ms cost-ordered: BEST {best_single:.3f} ms (what the ratios below are quoted against, round 5)")
 
 def run(assignment, chains, collect=None, ordered=False):
     """every shard of `assignment` alone on this GPU; chains: rrt_params.pass_chains.  collect: also record the tiles' measured
@@ -80,6 +85,6 @@ for name, m, chains, ordered, done in cases:
     ts, st = done if done else run(m, chains, ordered=ordered)
     cnt = np.bincount(m, minlength=N)
     print(f"{name:44s}: max shard {max(ts):.3f} ms  min {min(ts):.3f}  mean {np.mean(ts):.3f}  balance min/max {min(ts) / max(ts):.3f}  "
-          f"-> {full / max(ts):.2f}x of the single-GPU frame;  tiles per shard {cnt.min()}-{cnt.max()}, rounds with work "
+          f"-> {best_single / max(ts):.2f}x of the best single-GPU frame ({full / max(ts):.2f}x of the static-order one);  tiles per shard {cnt.min()}-{cnt.max()}, rounds with work "
           f"{max(s['rounds_with_work'] for s in st)}, in-line fall-backs {sum(s['overflow_waves'] for s in st)}", flush=True)
     print("    per shard [ms]: " + " ".join(f"{v:.3f}" for v in ts), flush=True)

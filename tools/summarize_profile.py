@@ -9,24 +9,29 @@ if ks:
     rows = list(csv.DictReader(open(ks[0])))
     with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
         f.write(open(ks[0]).read())
+    # kernel names end in <SPIN, MEDIA, DEBUG, ARITH>: the headline is the production instantiation in strict arithmetic
+    # (", false, 0>("); ARITH 2 = RRT_ARITH_FMAD, 1 = RRT_ARITH_FAST; the debug instantiations (conditioning account) are skipped
+    def kind(name):
+        if "raymarch_pixels" not in name or ", false, " not in name:
+            return None
+        return {"0": "kernel", "1": "fast_mode_kernel", "2": "fmad_mode_kernel"}.get(name.split(", false, ")[1][0])
     for r in rows:
-        if "raymarch" in r["Name"]:
-            fast = r["Name"].split("(")[1].strip().endswith("true>") if False else ", true>(" in r["Name"]
-            key = "fast_mode_kernel" if fast else "kernel"
+        key = kind(r["Name"])
+        if key:
             out[key] = r["Name"]; out[key + "_calls"] = int(r["Calls"]); out[key + "_avg_ms"] = float(r["AverageNs"]) / 1e6
 kt = glob.glob(f"{src}/trace/**/*kernel_trace.csv", recursive=True)
 if kt:
     # average over the full-frame dispatches only (bench.py also makes one tiny untimed pre-warm launch)
-    rows = [r for r in csv.DictReader(open(kt[0])) if "raymarch" in r["Kernel_Name"]]
-    for fast, key in ((False, "kernel"), (True, "fast_mode_kernel")):
-        sel = [r for r in rows if (", true>(" in r["Kernel_Name"]) == fast]
+    rows = [r for r in csv.DictReader(open(kt[0])) if kind(r["Kernel_Name"])]
+    for key in ("kernel", "fast_mode_kernel", "fmad_mode_kernel"):
+        sel = [r for r in rows if kind(r["Kernel_Name"]) == key]
         if sel:
             big = max(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) for r in sel)
             d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in sel
                  if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == big]
             out[key + "_calls"] = len(d); out[key + "_avg_ms"] = sum(d) / len(d)
             out[key] = [r["Kernel_Name"] for r in sel if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == big][0]
-    strict = [r for r in rows if ", true>(" not in r["Kernel_Name"]]
+    strict = [r for r in rows if kind(r["Kernel_Name"]) == "kernel"]
     if strict:
         r = max(strict, key=lambda r: int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]))      # the full-frame launch
         # rocprofv3's VGPR_Count column reads 48 for this 95-register kernel (half the 96 allocated); the compiler's
@@ -39,7 +44,7 @@ for name in ("fetch", "write", "sq"):
         continue
     acc = {}
     n = {}
-    allrows = [r for r in csv.DictReader(open(cs[0])) if "raymarch" in r["Kernel_Name"] and ", true>(" not in r["Kernel_Name"]]
+    allrows = [r for r in csv.DictReader(open(cs[0])) if kind(r["Kernel_Name"]) == "kernel"]
     big = max((int(r["Grid_Size"]) for r in allrows), default=0)
     for r in allrows:
         if int(r["Grid_Size"]) != big:      # skip bench.py's tiny pre-warm launch
