@@ -47,11 +47,22 @@ int main() {
     EXPECT(rrt_noise_table_plan(32.0f, &bytes, boxes) == RRT_OK && bytes > 0);
     EXPECT(rrt_noise_table_plan(-1.0f, &bytes, boxes) == RRT_ERR_INVALID_ARGUMENT);
     EXPECT(rrt_noise_table_plan(NAN, &bytes, boxes) == RRT_ERR_INVALID_ARGUMENT);
-    EXPECT(rrt_noise_table_plan(600.0f, &bytes, nullptr) == RRT_ERR_INVALID_ARGUMENT && bytes == 0);
-    for (int cov = RRT_TABLE_FULL; cov <= RRT_TABLE_COARSEST; ++cov)
-        for (float t0 : {-9000.0f, -50.0f, 0.0f, 31.5f, 495.0f, 9000.0f})
-            for (float span : {0.0f, 0.5f, 10.0f, 1000.0f})
-                (void)rrt_noise_table_plan_window(t0, t0 + span, cov, &bytes, boxes);
+    EXPECT(rrt_noise_table_plan_window(0.0f, 600.0f, RRT_TABLE_FULL | RRT_TABLE_DENSE, &bytes, nullptr) == RRT_ERR_INVALID_ARGUMENT && bytes == 0);
+    EXPECT(rrt_noise_table_plan(600.0f, &bytes, nullptr) == RRT_OK && bytes > 0);          // round 5: addressable in the banded layout
+    int banded = 0, n_bands = 0; float w_min = 0, w_scale = 0;
+    std::vector<int32_t> band_boxes(3 * 64 * 6), acc_boxes(24);
+    for (int layout : {0, (int)RRT_TABLE_BANDED, (int)RRT_TABLE_DENSE})
+        for (int cov = RRT_TABLE_FULL; cov <= RRT_TABLE_COARSEST; ++cov)
+            for (float t0 : {-9000.0f, -50.0f, 0.0f, 31.5f, 495.0f, 9000.0f})
+                for (float span : {0.0f, 0.5f, 10.0f, 1000.0f}) {
+                    (void)rrt_noise_table_plan_window(t0, t0 + span, cov | layout, &bytes, boxes);
+                    (void)rrt_noise_table_plan_layout(t0, t0 + span, cov | layout, &banded, &n_bands, &w_min, &w_scale, band_boxes.data(), 64, acc_boxes.data());
+                }
+    EXPECT(rrt_noise_table_plan_layout(495.0f, 505.0f, RRT_TABLE_FULL, &banded, &n_bands, &w_min, &w_scale, band_boxes.data(), 64, acc_boxes.data()) == RRT_OK
+           && banded == 1 && n_bands >= 1 && n_bands <= 64);
+    EXPECT(rrt_noise_table_plan_layout(495.0f, 505.0f, RRT_TABLE_FULL, &banded, &n_bands, nullptr, nullptr, band_boxes.data(), 1, nullptr) == RRT_ERR_INVALID_ARGUMENT);   // cap_bands too small
+    EXPECT(rrt_noise_table_plan_layout(495.0f, 505.0f, RRT_TABLE_FULL, nullptr, &n_bands, nullptr, nullptr, nullptr, 0, nullptr) == RRT_ERR_INVALID_ARGUMENT);
+    EXPECT(rrt_noise_table_plan_window(0.0f, 1.0f, RRT_TABLE_BANDED | RRT_TABLE_DENSE, &bytes, boxes) == RRT_ERR_INVALID_ARGUMENT);
     EXPECT(rrt_noise_table_plan_window(2.0f, 1.0f, RRT_TABLE_FULL, &bytes, boxes) == RRT_ERR_INVALID_ARGUMENT);
     EXPECT(rrt_noise_table_plan_window(0.0f, 1.0f, 7, &bytes, boxes) == RRT_ERR_INVALID_ARGUMENT);
     EXPECT(rrt_noise_table_plan_window(0.0f, 1.0f, RRT_TABLE_FULL, nullptr, nullptr) == RRT_OK);
