@@ -175,6 +175,7 @@ int rrt_abi_version(void);
 const char* rrt_status_string(int status);
 const char* rrt_last_hip_error(void);          /* thread-local text of the last HIP failure */
 int rrt_device_count(int* count);
+int rrt_path_auto_max_rays(void);             /* RRT_PATH_AUTO takes the three-pass path for launches of at most this many rays (1 500 000) */
 /* config.h defaults into the first `size` bytes of an rrt_params and struct_size = size.  Call it through the macro below, so
  * that `size` is the sizeof of the header the CALLER was compiled against: the library then knows which fields the caller
  * has.  Accepted sizes: this header's, and ABI 4's 48 bytes (fields the caller does not have read as their defaults); any

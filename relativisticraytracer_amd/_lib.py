@@ -64,6 +64,7 @@ SYMBOLS = [
     ("rrt_status_string", C.c_char_p, [_i]),
     ("rrt_last_hip_error", C.c_char_p, []),
     ("rrt_device_count", _i, [C.POINTER(_i)]),
+    ("rrt_path_auto_max_rays", _i, []),
     ("rrt_params_init", _i, [_vp, C.c_uint32]),
     ("rrt_effects_default", _i, [_fx]),
     ("rrt_sky_create", _i, [_vp, _i, _i, C.POINTER(_ull)]),

@@ -286,7 +286,7 @@ int main(int argc, char** argv) {
             // launch takes the single kernel; a wash when frames overlap, and measured harmful on the three-pass path's two
             // chains (it piles every expensive tile into the first chain: an eighth of a 4K frame 5.15 -> 5.45 ms, of a
             // disk-heavy one 7.7 -> 10.6; profiles/r04_shard_kernel_times_*.txt), which is what small launches with a pool take
-            const bool three_pass_likely = workspace_gib > 0 && (long long)w * rows <= 1500000ll;
+            const bool three_pass_likely = workspace_gib > 0 && (long long)w * rows <= (long long)rrt_path_auto_max_rays();   // RRT_PATH_AUTO's own threshold
             if ((tile_order == 1 || (tile_order < 0 && kSlots == 1 && !three_pass_likely)) && (rc = rrt_tile_order_create(&D.order[s])) != RRT_OK)
                 return fail("tile order", rc);
         }

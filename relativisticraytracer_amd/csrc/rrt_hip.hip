@@ -889,6 +889,10 @@ extern "C" {
 
 int rrt_abi_version(void) { return RRT_ABI_VERSION; }
 
+/* RRT_PATH_AUTO's threshold, for hosts that size their own policy on it (the drivers leave rrt_tile_order off for launches
+ * that will take the three-pass path): one definition instead of a copy in every driver */
+int rrt_path_auto_max_rays(void) { return (int)kThreePassMaxRays; }
+
 const char* rrt_status_string(int s) {
     switch (s) {
         case RRT_OK: return "ok";

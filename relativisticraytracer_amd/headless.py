@@ -106,7 +106,7 @@ def main(argv=None):
     # cost-ordered dispatch pays on single-kernel launches whose frames do not overlap; on the three-pass path (small launches
     # with a pool) it piles the expensive tiles into the first of the two chains and was measured slower: auto leaves it off there
     my_rays = w * sharding.shard_rows(h, args.tile_rows, rank, world)
-    three_pass_likely = bool(pools) and my_rays <= 1_500_000
+    three_pass_likely = bool(pools) and my_rays <= rrt._lib.load().rrt_path_auto_max_rays()      # RRT_PATH_AUTO's own threshold
     use_order = args.tile_order == "on" or (args.tile_order == "auto" and n_slots == 1 and not three_pass_likely)
     orders = [rrt.TileOrder() for _ in range(n_slots)] if use_order else []
     prms = [rrt.RenderParams(spin=args.spin, volumetrics=0 if args.no_volumetrics else 1,
