@@ -204,6 +204,11 @@ def test_bench_self_launches_its_ranks():
     assert len(ph["per_rank_gather_ms"]) == 2 and ph["rank0_assemble_ms"] >= 0 and 0 < ph["render_balance_min_over_max"] <= 1
     assert one["ms_per_step"] > 0 and one["value"] > 0 and len(one["per_rank_render_ms"]) == 2
     assert mg["frames_in_flight"] == 3
+    # round 5: the denominator of a scaling figure travels with the line -- rank 0 alone on the same frame, same run, best of the
+    # static and the cost-ordered dispatch, and its bytes equal the gathered frame's
+    ref = mg["single_gpu_reference"]
+    assert mg["single_gpu_reference_ms"] == min(ref["static_order_ms"], ref["cost_ordered_ms"]) > 0
+    assert ref["same_bytes_as_the_gathered_frame"] is True and mg["speedup_vs_single_gpu_reference"] > 0
 
 
 @pytest.mark.gpu
