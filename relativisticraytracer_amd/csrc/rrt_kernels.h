@@ -750,8 +750,17 @@ __global__ void pool_next_round(DeferCounters* c, unsigned capacity, int last) {
 }
 
 /* ---- pass 2: densities + emission of every pooled sample row, grid-stride over the pool ---- */
+/* Round 5: pass 2 is the one latency-bound kernel with spare registers -- 40 % of its wave-cycles sit in s_waitcnt at 3.8
+ * resident waves per SIMD (profiles/r05_pmc_diag_before_nt.txt) -- and its code fits 64 VGPRs with two spilled registers: 8 waves
+ * per SIMD (the grid is exactly 8 192 waves) instead of 5 is worth 3 % of a full disk-heavy three-pass frame (key 1 56.9 -> 55.3 ms,
+ * from inside the disk 57.5 -> 55.7; 6 and 7 waves: < 1 %; a rank's share, whose pass 2 already runs under the other chain's
+ * march, does not move: profiles/r05_eval_waves_ab.txt).  The in-line kernels, which share the code, gain nothing from more
+ * waves (round 3) and keep 5. */
+#ifndef RRT_EVAL_WAVES
+#define RRT_EVAL_WAVES 8
+#endif
 template <int ARITH, int MEDIA>
-__global__ __launch_bounds__(256) void eval_sample_rows(const FrameArgs a) {
+__global__ __launch_bounds__(256, RRT_EVAL_WAVES) void eval_sample_rows(const FrameArgs a) {
     const int lane = threadIdx.x & 63;
     const unsigned n_blk = min(a.ctr->next_block, a.block_capacity);
     const unsigned total = n_blk * kBlockRows;
