@@ -14,6 +14,16 @@ __global__ void read_then_dirty(unsigned* buf, unsigned* out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { out[i] = buf[i]; buf[i] += 7u; }
 }
+// variant 2's kernels: word 1 of the header is a counter every thread bumps (atomics), word 2 counts rounds, the rest is scribbled on
+__global__ void bump_header(unsigned* hdr, unsigned* far_rows, size_t n_words) {
+    atomicAdd(&hdr[1], 1u);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (4 + i < n_words) hdr[4 + i] = 0xDEAD0000u + (unsigned)i;
+    far_rows[i] = hdr[2];
+}
+__global__ void read_header(const unsigned* hdr, unsigned* seen, int round) { if (threadIdx.x == 0) seen[round] = hdr[1]; }
+__global__ void next_round(unsigned* hdr) { hdr[1] = 0u; hdr[2] += 1u; }
+
 int main() {
     const size_t sizes[] = {256, 4096, 256 + 16 * 1000, 256 + 16 * 16200, 256 + 16 * 129600, (size_t)8 << 20};
     const size_t offsets[] = {0, 256, 4096 + 256};
@@ -55,6 +65,51 @@ int main() {
             if (bad) { printf("  (first at word %zu = 0x%08x)\n", first, h[first]); ++bad_total; }
         }
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); CK(hipFree(base)); CK(hipFree(out));
+    }
+    // variant 2: the shape of the library's captured three-pass launch -- a 64 MB allocation whose first `hdr` bytes are the memset
+    // region, a non-blocking capture stream in global mode, per round: a kernel with atomics on the header + writes far into
+    // the allocation, a reader of the header, a one-thread kernel that rewrites counters; then a device-to-pinned-host copy of the
+    // counters; between replays a live memset of ANOTHER buffer on the null stream (torch's d3.zero_()).  `first_words` must read
+    // (rounds, 0, ...) after every replay if the memset node cleared the header.
+    {
+        hipStream_t cs;
+        CK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        unsigned char* big; unsigned* other; unsigned* seen;
+        const size_t total = (size_t)64 << 20;
+        CK(hipMalloc(&big, total)); CK(hipMalloc(&other, 1 << 20)); CK(hipMalloc(&seen, 4096));
+        for (size_t hdr : {(size_t)1792, (size_t)4352, (size_t)(256 + 16 * 16200 + 255) & ~(size_t)255}) {
+            CK(hipMemset(big, 0xCD, total));
+            auto enqueue = [&](hipStream_t st) -> int {
+                CK(hipMemsetAsync(big, 0, hdr, st));
+                for (int round = 0; round < 3; ++round) {
+                    hipLaunchKernelGGL(bump_header, dim3(64), dim3(64), 0, st, reinterpret_cast<unsigned*>(big), reinterpret_cast<unsigned*>(big + ((size_t)32 << 20)), hdr / 4);
+                    hipLaunchKernelGGL(read_header, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned*>(big), seen, round);
+                    hipLaunchKernelGGL(next_round, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned*>(big));
+                }
+                CK(hipMemcpyAsync(h_pinned, big, 64, hipMemcpyDeviceToHost, st));
+                return 0;
+            };
+            if (enqueue(cs)) return 2;                                  // live once, as the library's workspace is used before the capture
+            CK(hipStreamSynchronize(cs));
+            hipGraph_t g; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(cs, hipStreamCaptureModeGlobal));
+            if (enqueue(cs)) return 2;
+            CK(hipStreamEndCapture(cs, &g));
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            for (int rep = 0; rep < 4; ++rep) {
+                CK(hipMemsetAsync(other, 0, 1 << 20, nullptr));         // live work on the null stream in between
+                CK(hipStreamSynchronize(nullptr));
+                CK(hipGraphLaunch(ge, cs));
+                CK(hipStreamSynchronize(cs));
+                unsigned h[16];
+                CK(hipMemcpy(h, seen, sizeof(h), hipMemcpyDeviceToHost));
+                // seen[round] = header word 1 (a counter bump_header adds 64*64 to per round, next_round resets) as the reader saw it
+                const bool ok = h[0] == 64u * 64u && h[1] == 64u * 64u && h[2] == 64u * 64u && h_pinned[2] == 3u;
+                printf("variant 2 header %6zu bytes replay %d: reader saw %u %u %u, rounds counter %u%s\n", hdr, rep, h[0], h[1], h[2], h_pinned[2], ok ? "" : "   <-- STALE HEADER");
+                if (!ok) ++bad_total;
+            }
+            CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+        }
     }
     printf("%s\n", bad_total ? "MEMSET NODE DEFECT REPRODUCED" : "memset nodes cleared their buffers on every replay: not reproduced in isolation");
     return 0;
