@@ -111,6 +111,61 @@ int main() {
             CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
         }
     }
+    // variant 3: variant 0's graph instantiated the way torch.cuda.graph instantiates (hipGraphInstantiateWithFlags,
+    // hipGraphInstantiateFlagAutoFreeOnLaunch) -- under torch's capture the defect reproduces (tools/graph_memset_repro_torch.py)
+    for (size_t bytes : {(size_t)1792, (size_t)4352, (size_t)259584}) {
+        const size_t n = bytes / 4;
+        unsigned *buf, *out;
+        CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&out, bytes));
+        CK(hipMemset(buf, 0xAB, bytes));
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        CK(hipMemsetAsync(buf, 0, bytes, st));
+        hipLaunchKernelGGL(read_then_dirty, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, buf, out, n);
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiateWithFlags(&ge, g, hipGraphInstantiateFlagAutoFreeOnLaunch));
+        std::vector<unsigned> h(n);
+        for (int rep = 0; rep < 4; ++rep) {
+            CK(hipGraphLaunch(ge, st));
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(h.data(), out, bytes, hipMemcpyDeviceToHost));
+            size_t bad = 0, first = n, last = 0;
+            for (size_t i = 0; i < n; ++i) if (h[i] != 0u) { if (first == n) first = i; last = i; ++bad; }
+            printf("variant 3 (AutoFreeOnLaunch) bytes %7zu replay %d: %zu of %zu words not cleared", bytes, rep, bad, n);
+            if (bad) { printf("   <-- STALE: words %zu..%zu, first = 0x%08x", first, last, h[first]); ++bad_total; }
+            printf("\n");
+        }
+        CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); CK(hipFree(buf)); CK(hipFree(out));
+    }
+    // variant 4: the template graph is DESTROYED right after instantiation, as torch.cuda.graph does (it keeps only the executable
+    // graph), and the host heap is churned before the launches: does the executable graph still own its memset parameters?
+    for (size_t bytes : {(size_t)1792, (size_t)4352, (size_t)259584}) {
+        const size_t n = bytes / 4;
+        unsigned *buf, *out;
+        CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&out, bytes));
+        CK(hipMemset(buf, 0xAB, bytes));
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        CK(hipMemsetAsync(buf, 0, bytes, st));
+        hipLaunchKernelGGL(read_then_dirty, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, buf, out, n);
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiateWithFlags(&ge, g, hipGraphInstantiateFlagAutoFreeOnLaunch));
+        CK(hipGraphDestroy(g));
+        std::vector<std::vector<char>> churn;
+        for (int k = 0; k < 2000; ++k) churn.emplace_back(64 + 37 * (k % 50), (char)k);       // reuse whatever the template graph freed
+        std::vector<unsigned> h(n);
+        for (int rep = 0; rep < 4; ++rep) {
+            CK(hipGraphLaunch(ge, st));
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(h.data(), out, bytes, hipMemcpyDeviceToHost));
+            size_t bad = 0, first = n, last = 0;
+            for (size_t i = 0; i < n; ++i) if (h[i] != 0u) { if (first == n) first = i; last = i; ++bad; }
+            printf("variant 4 (template graph destroyed) bytes %7zu replay %d: %zu of %zu words not cleared", bytes, rep, bad, n);
+            if (bad) { printf("   <-- STALE: words %zu..%zu, first = 0x%08x", first, last, h[first]); ++bad_total; }
+            printf("\n");
+        }
+        CK(hipGraphExecDestroy(ge)); CK(hipFree(buf)); CK(hipFree(out));
+    }
     printf("%s\n", bad_total ? "MEMSET NODE DEFECT REPRODUCED" : "memset nodes cleared their buffers on every replay: not reproduced in isolation");
     return 0;
 }
