@@ -1300,6 +1300,7 @@ def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
     ample, starved = rrt.Workspace(512 << 20), rrt.Workspace(13 << 20)     # 13 MiB: the smallest useful pool
     mid = rrt.Workspace(64 << 20)                                          # two chains need >= 4096 blocks: rounds AND chains
     nt = rrt.NoiseTable(30.0)
+    nt_banded = rrt.NoiseTable.window(0.0, 30.0, rrt.TABLE_FULL | rrt.TABLE_BANDED)
     order = rrt.TileOrder()
     order3 = rrt.TileOrder()
     try:
@@ -1394,8 +1395,26 @@ def test_randomized_sweep_every_launch_variant_matches_oracle(ctx, po, sky):
             torch.cuda.synchronize()
             assert torch.equal(frame, want), (tag, "tile map", n, R)
             tm.destroy()
+            # round 5: the BANDED table layout (forced: near the origin of the clock the automatic choice is dense) -- the oracle's bytes,
+            # single kernel and three-pass, no clamped read; and the within-tolerance modes are one function on every path
+            r = g.render_gpu(w, h, spin, 1, cam, t, tex, fx=fx, noise_table=nt_banded.id)
+            assert np.array_equal(r["rgba8"], o["rgba8"]) and same_bits(r["ldr"], o["ldr"]) and int(r["lut_oob"][0]) == 0, (tag, "banded table")
+            out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+            rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=spin, workspace=mid.id, path_policy=2, pool_rounds=48,
+                                                                              pass_chains=1 + case % 2, noise_table=nt_banded.id))
+            torch.cuda.synchronize()
+            assert torch.equal(out, want), (tag, "banded table, three-pass")
+            mode = 2 - case % 2                       # RRT_ARITH_FMAD on even scenes, RRT_ARITH_FAST on odd ones
+            rm = g.render_gpu(w, h, spin, 1, cam, t, tex, fx=fx, arith_mode=mode)["rgba8"]
+            wantm = torch.from_numpy(rm.reshape(-1)).cuda()
+            for kw in (dict(noise_table=nt.id), dict(noise_table=nt_banded.id, workspace=starved.id, path_policy=2, pool_rounds=64),
+                       dict(workspace=mid.id, path_policy=2, pool_rounds=48, pass_chains=2, tile_order=order3.id)):
+                out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+                rrt.launch_raymarch(out, w, h, t, cam, tex, fx, rrt.RenderParams(spin=spin, arith_mode=mode, **kw))
+                torch.cuda.synchronize()
+                assert torch.equal(out, wantm), (tag, "mode", mode, kw)
         assert overflowed > 0          # the starved pool did exercise the overflow route somewhere in the sweep
         info = order.info()
         assert info["ordered_launches"] >= info["launches"] // 2       # every scene's second launch (at least) was cost-ordered
     finally:
-        ample.destroy(); starved.destroy(); mid.destroy(); nt.destroy(); order.destroy(); order3.destroy()
+        ample.destroy(); starved.destroy(); mid.destroy(); nt.destroy(); nt_banded.destroy(); order.destroy(); order3.destroy()
