@@ -24,7 +24,7 @@ from relativisticraytracer_amd import build  # noqa: E402
 
 def listing():
     d = tempfile.mkdtemp(prefix="rrt_isa_")
-    cmd = [build.hipcc_path()] + [f for f in build.HIPCC_FLAGS if f != "-shared"] + ["-save-temps", "-c"] + build.SOURCES + ["-o", os.path.join(d, "x.o")]
+    cmd = [build.hipcc_path()] + [f for f in build.HIPCC_FLAGS if f != "-shared"] + os.environ.get("RRT_ISA_FLAGS", "").split() + ["-save-temps", "-c"] + build.SOURCES + ["-o", os.path.join(d, "x.o")]
     subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     f = [x for x in os.listdir(d) if x.endswith("gfx950.s")][0]
     return open(os.path.join(d, f)).read().split("\n")
