@@ -236,7 +236,14 @@ def main():
     table_build_ms = (time.perf_counter() - t_build0) * 1e3
     prms = [rrt.RenderParams(spin=args.spin, volumetrics=1, workspace=pools[j].id if pools else 0,
                              noise_table=ntab.id if ntab else 0,
+                             # several frames in flight: ONE chain per launch -- the other frames fill a launch's tails and the second
+                             # chain's streams only compete with them (profiles/r05_sustained_chains.txt: a rank's share of the 4K
+                             # frame from inside the disk 7.4 -> 6.8 ms per frame, of the bench frame 4.9 -> 4.8)
+                             pass_chains=1 if pipeline else 0,
                              path_policy=int(os.environ.get("RRT_PATH_POLICY", "0"))) for j in range(n_slots)]
+    # the one-frame-at-a-time leg: the library's own choice (two chains)
+    prm_one = rrt.RenderParams(spin=args.spin, volumetrics=1, workspace=pools[0].id if pools else 0, noise_table=ntab.id if ntab else 0,
+                               path_policy=int(os.environ.get("RRT_PATH_POLICY", "0")))
 
     kernel_ms = []
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -344,7 +351,7 @@ def main():
             def render1(buf, slot):
                 e0, e1 = ev1[it1["i"]]
                 e0.record()
-                rrt.launch_raymarch_tiles(buf, w, h, R, rank, world, 1.0, cam, tex, fx, prms[0])
+                rrt.launch_raymarch_tiles(buf, w, h, R, rank, world, 1.0, cam, tex, fx, prm_one)
                 e1.record()
 
             fs1 = sharding.FrameSharder(w, h, R, rank, world, dev, render1, assemble, assemble_all=assemble_all,
@@ -629,6 +636,7 @@ def main():
                                                               "cost-ordered dispatch, measured in this run while the other ranks waited",
                                  "phases": phases, "one_frame_at_a_time": one_at_a_time,
                                  "frames_in_flight": fs.n_slots,
+                                 "chains_per_launch": ("one (several frames in flight fill each other's tails)" if fs.pipeline else "automatic (two)"),
                                  "frames_in_flight_note": "default 3: chosen on ONE GPU rendering a single rank's share "
                                                           "(profiles/r02_frames_in_flight.txt); provisional until a run on >= 2 GPUs"}
         

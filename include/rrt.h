@@ -133,7 +133,10 @@ typedef struct rrt_params {
     int32_t pass_chains;     /* three-pass path: 0 (default) = automatic -- a launch of >= 2 048 wavefronts is cut in two
                                 along its dispatch order and the halves run their march -> evaluate -> composite chains
                                 side by side (the workspace's own second stream), so that one half's evaluation fills the
-                                other half's march tail; 1 = one chain; 2 = two whenever possible.  Same bytes.           */
+                                other half's march tail; 1 = one chain; 2 = two whenever possible.  Same bytes.  A caller that
+                                keeps SEVERAL launches in flight on streams of its own (frames of an animation) should ask for
+                                1: the other frames already fill a launch's tails, and the extra streams only get in each
+                                other's way (a rank's share of a 4K frame, three in flight: 6.8 instead of 7.4 ms).           */
     int32_t nudge_ulps;      /* conditioning probe (ABI 5).  0 (default): primary rays exactly as raymarcher.cu:27-34 forms
                                 them.  K > 0: every component of every pixel's normalised primary direction is moved by a
                                 pseudo-random whole number of ulps in [-K, K] (a hash of pixel and nudge_seed; the oracle has

@@ -112,6 +112,7 @@ def main(argv=None):
     prms = [rrt.RenderParams(spin=args.spin, volumetrics=0 if args.no_volumetrics else 1,
                              noise_table=0, tile_order=orders[j].id if orders else 0,
                              arith_mode=1 if args.fast else 0, workspace=pools[j].id if pools else 0,
+                             pass_chains=1 if n_slots >= 2 else 0,      # frames in flight fill each other's tails: one chain per launch
                              path_policy=int(os.environ.get("RRT_PATH_POLICY", "0"))) for j in range(n_slots)]
     path = camera_paths.CameraPath(args.path) if args.path >= 0 else None
     state = {"t": 0.0, "cam": rrt.CameraState.default(), "table": 0}
