@@ -238,7 +238,8 @@ def main():
                              noise_table=ntab.id if ntab else 0,
                              # several frames in flight: ONE chain per launch -- the other frames fill a launch's tails and the second
                              # chain's streams only compete with them (profiles/r05_sustained_chains.txt: a rank's share of the 4K
-                             # frame from inside the disk 7.4 -> 6.8 ms per frame, of the bench frame 4.9 -> 4.8)
+                             # frame from inside the disk 7.4 -> 6.8 ms per frame, of the bench frame 4.9 -> 4.8); the PATH is chosen
+                             # per rank below (tune_path)
                              pass_chains=1 if pipeline else 0,
                              path_policy=int(os.environ.get("RRT_PATH_POLICY", "0"))) for j in range(n_slots)]
     # the one-frame-at-a-time leg: the library's own choice (two chains)
@@ -279,6 +280,41 @@ def main():
         dist.gather(probe, [torch.zeros_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
         dist.barrier()
     torch.cuda.synchronize()
+    # Rank-local choice of the path a rank's share takes while several frames are in flight (same bytes either way; untimed set-up, like
+    # the table build).  The other frames fill a launch's drain, which is all the three-pass path is for, so the plain single kernel
+    # (4 % less work, no pool traffic) is usually the fastest way through: 4.56 / 6.21 / 6.56 ms per frame on the bench / key-1 / skimmer
+    # views against 4.74 / 6.61 / 6.85 three-pass with three in flight -- UNLESS the share holds a wavefront that takes longer than the
+    # frames in flight together: a slot's next frame waits for it (the disk-grazing view's middle shards: 19 ms, 7.5 against 6.2 ms per
+    # frame).  The camera is fixed here, so each rank times both on its own share (two bursts of 4 x slots frames each) and keeps the
+    # faster; profiles/r05_sustained_chains.txt.  RRT_PATH_POLICY pins the path instead.
+    path_tuning = None
+    if pipeline and fs.streams is not None and "RRT_PATH_POLICY" not in os.environ:
+        def burst_ms(policy):
+            for p in prms:
+                p.path_policy = policy
+            best = 1e9
+            for _ in range(3):                      # the first burst also warms the path's code objects
+                torch.cuda.synchronize(dev)
+                t0b = time.perf_counter()
+                for k in range(4 * n_slots):
+                    with torch.cuda.stream(fs.streams[k % n_slots]):
+                        rrt.launch_raymarch_tiles(fs.locals[k % n_slots], w, h, R, rank, world, 1.0, cam, tex, fx, prms[k % n_slots])
+                torch.cuda.synchronize(dev)
+                best = min(best, (time.perf_counter() - t0b) * 1e3 / (4 * n_slots))
+            return best
+        cand = {0: burst_ms(0), 1: burst_ms(1)}
+        pick = min(cand, key=cand.get)
+        for p in prms:
+            p.path_policy = pick
+        mine = {"rank": rank, "picked": "single kernel, media in line" if pick == 1 else "automatic (three-pass, one chain, for a small share)",
+                "ms_per_frame_three_pass_auto": round(cand[0], 3), "ms_per_frame_single_kernel": round(cand[1], 3)}
+        allt = [None] * world
+        dist.all_gather_object(allt, mine)
+        path_tuning = {"per_rank": allt, "note": "rank-local, untimed set-up: each rank's share sustained through both paths with the "
+                                                 "configured frames in flight, the faster one kept (same bytes)"}
+    elif pipeline:
+        path_tuning = {"pinned": "RRT_PATH_POLICY=" + os.environ.get("RRT_PATH_POLICY", "0")}
+
     dog.disarm()
     dog.arm(args.run_timeout, "timed frames and their legs")
 
@@ -636,7 +672,7 @@ def main():
                                                               "cost-ordered dispatch, measured in this run while the other ranks waited",
                                  "phases": phases, "one_frame_at_a_time": one_at_a_time,
                                  "frames_in_flight": fs.n_slots,
-                                 "chains_per_launch": ("one (several frames in flight fill each other's tails)" if fs.pipeline else "automatic (two)"),
+                                 "path_per_launch": path_tuning if fs.pipeline else "automatic (three-pass in two chains for a small share)",
                                  "frames_in_flight_note": "default 3: chosen on ONE GPU rendering a single rank's share "
                                                           "(profiles/r02_frames_in_flight.txt); provisional until a run on >= 2 GPUs"}
         

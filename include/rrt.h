@@ -136,7 +136,9 @@ typedef struct rrt_params {
                                 other half's march tail; 1 = one chain; 2 = two whenever possible.  Same bytes.  A caller that
                                 keeps SEVERAL launches in flight on streams of its own (frames of an animation) should ask for
                                 1: the other frames already fill a launch's tails, and the extra streams only get in each
-                                other's way (a rank's share of a 4K frame, three in flight: 6.8 instead of 7.4 ms).           */
+                                other's way (a rank's share of a 4K frame, three in flight: 6.8 instead of 7.4 ms).  With four
+                                or more in flight RRT_PATH_SINGLE is usually faster still -- unless the view has a wavefront
+                                that takes longer than the frames in flight together.                   */
     int32_t nudge_ulps;      /* conditioning probe (ABI 5).  0 (default): primary rays exactly as raymarcher.cu:27-34 forms
                                 them.  K > 0: every component of every pixel's normalised primary direction is moved by a
                                 pseudo-random whole number of ulps in [-K, K] (a hash of pixel and nudge_seed; the oracle has

@@ -405,7 +405,11 @@ int main(int argc, char** argv) {
             rrt_params prm; rrt_params_default(&prm);
             prm.spin = spin; prm.arith_mode = fast ? RRT_ARITH_FAST : RRT_ARITH_STRICT;
             prm.workspace = D.pool[slot]; prm.noise_table = D.noise_table; prm.tile_order = D.order[slot];
-            prm.pass_chains = kSlots >= 2 ? 1 : 0;     // frames in flight fill each other's tails: one chain per launch (rrt.h)
+            // frames in flight fill each other's drains: ONE chain per launch (the second chain's streams only compete with the other
+            // frames: 2-7 % per frame, profiles/r05_sustained_chains.txt).  The plain single kernel would be faster still on most views,
+            // but its longest wavefront (up to 19 ms on a disk-grazing view) bounds a slot's frame rate; a moving camera keeps the
+            // path that is never slow
+            prm.pass_chains = kSlots >= 2 ? 1 : 0;
             void* dst = collective ? D.tiles[slot] : frame[slot];
             if (collective) rc = rrt_launch_raymarch_tiles(dst, w, h, tile_rows, d, gpus, sim_t, &cam, D.sky, &fx, &prm, D.stream[slot]);
             else rc = rrt_launch_raymarch(dst, w, h, sim_t, &cam, D.sky, &fx, &prm, D.stream[slot]);

@@ -112,7 +112,12 @@ def main(argv=None):
     prms = [rrt.RenderParams(spin=args.spin, volumetrics=0 if args.no_volumetrics else 1,
                              noise_table=0, tile_order=orders[j].id if orders else 0,
                              arith_mode=1 if args.fast else 0, workspace=pools[j].id if pools else 0,
-                             pass_chains=1 if n_slots >= 2 else 0,      # frames in flight fill each other's tails: one chain per launch
+                             # frames in flight fill each other's drains: ONE chain per launch (the second chain's streams only compete with
+                             # the other frames: 2-7 % per frame, profiles/r05_sustained_chains.txt).  The plain single kernel would be
+                             # faster still on most views (0.98-1.0 of a rank's fair share against 0.86-0.96) but its longest wavefront
+                             # -- up to 19 ms on a disk-grazing view -- bounds a slot's frame rate: this driver's camera moves, so it keeps
+                             # the path that is never slow (bench.py, whose camera is fixed, times both at start-up)
+                             pass_chains=1 if n_slots >= 2 else 0,
                              path_policy=int(os.environ.get("RRT_PATH_POLICY", "0"))) for j in range(n_slots)]
     path = camera_paths.CameraPath(args.path) if args.path >= 0 else None
     state = {"t": 0.0, "cam": rrt.CameraState.default(), "table": 0}

@@ -203,7 +203,7 @@ def test_bench_self_launches_its_ranks():
     assert len(ph["per_rank_render_ms"]) == 2 and all(v > 0 for v in ph["per_rank_render_ms"])
     assert len(ph["per_rank_gather_ms"]) == 2 and ph["rank0_assemble_ms"] >= 0 and 0 < ph["render_balance_min_over_max"] <= 1
     assert one["ms_per_step"] > 0 and one["value"] > 0 and len(one["per_rank_render_ms"]) == 2
-    assert mg["frames_in_flight"] == 3 and mg["chains_per_launch"].startswith("one")
+    assert mg["frames_in_flight"] == 3 and len(mg["path_per_launch"]["per_rank"]) == 2
     # round 5: the denominator of a scaling figure travels with the line -- rank 0 alone on the same frame, same run, best of the
     # static and the cost-ordered dispatch, and its bytes equal the gathered frame's
     ref = mg["single_gpu_reference"]

@@ -98,10 +98,11 @@ if os.environ.get("RRT_SUSTAINED", "1") == "1":
     streams = [torch.cuda.Stream() for _ in range(slots)]
     bufs = [torch.zeros(rrt.tile_shard_rows(H, R, 0, N) * W * 4, dtype=torch.uint8, device="cuda") for _ in range(slots)]
     tm = rrt.TileMap(H, R, N, modulo)
-    for label, chains in (("t mod N, two chains, 3 frames in flight", 0), ("t mod N, ONE chain, 3 frames in flight (the drivers)", 1)):
+    for label, chains, policy in (("t mod N, two chains, 3 frames in flight", 0, 2), ("t mod N, ONE chain, 3 frames in flight (the drivers)", 1, 2),
+                                  ("t mod N, SINGLE KERNEL in line, 3 frames in flight", 1, 1)):
         ts = []
         for sh in range(N):
-            prms = [rrt.RenderParams(spin=spin, noise_table=nt.id, workspace=pools[j].id, path_policy=2, pass_chains=chains) for j in range(slots)]
+            prms = [rrt.RenderParams(spin=spin, noise_table=nt.id, workspace=pools[j].id, path_policy=policy, pass_chains=chains) for j in range(slots)]
             def burst(frames):
                 cur = torch.cuda.current_stream()
                 for s in streams:
@@ -111,7 +112,7 @@ if os.environ.get("RRT_SUSTAINED", "1") == "1":
                 for s in streams:
                     cur.wait_stream(s)
             ts.append(timed(lambda: burst(12)) / 12)
-        print(f"{label:52s}: max shard {max(ts):.3f} ms per frame  min {min(ts):.3f}  mean {np.mean(ts):.3f}  "
+        print(f"{label:66s}: max shard {max(ts):.3f} ms per frame  min {min(ts):.3f}  mean {np.mean(ts):.3f}  "
               f"-> {best_single / max(ts):.2f}x of the best single-GPU frame ({full / max(ts):.2f}x of the static-order one), sustained", flush=True)
         print("    per shard [ms]: " + " ".join(f"{v:.3f}" for v in ts), flush=True)
     tm.destroy()

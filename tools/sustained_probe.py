@@ -1,5 +1,6 @@
 """dev tool (GPU): sustained time per frame of ONE rank's share (shard 0 of 8, 16-row tiles, three-pass, two chains) of a 4K view with
 1 ... 6 frames in flight (own stream + own share of a 16 GiB pool each), against the rank's fair share of the best single-GPU frame.
+RRT_POLICY=1: the single kernel (media in line) instead of the three-pass path; RRT_CHAINS=1: one chain per launch; RRT_ORDER=1: cost-ordered dispatch, one rrt_tile_order object per frame in flight.
 usage: sustained_probe.py [view] [shard]"""
 import os, sys
 import torch
@@ -32,11 +33,13 @@ single = min(timed(lambda: rrt.launch_raymarch(full, W, H, t, cam, tex, fx, rrt.
              timed(lambda: rrt.launch_raymarch(full, W, H, t, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id, tile_order=o.id)), reps=4))
 print(f"{view}: best single-GPU frame {single:.3f} ms -> a rank's fair share {single / N:.3f} ms", flush=True)
 rows = rrt.tile_shard_rows(H, R, sh, N)
-for slots in (1, 2, 3, 4, 6):
+for slots in (1, 2, 3, 4, 6, 8):
     pools = [rrt.Workspace((16 << 30) // slots) for _ in range(slots)]
     streams = [torch.cuda.Stream() for _ in range(slots)]
     bufs = [torch.zeros(rows * W * 4, dtype=torch.uint8, device="cuda") for _ in range(slots)]
-    prms = [rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=pools[j].id, path_policy=2,
+    orders = [rrt.TileOrder() for _ in range(slots)] if os.environ.get("RRT_ORDER", "0") == "1" else None
+    prms = [rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=pools[j].id, path_policy=int(os.environ.get("RRT_POLICY", "2")),
+                             tile_order=orders[j].id if orders else 0,
                              pass_chains=int(os.environ.get("RRT_CHAINS", "0"))) for j in range(slots)]
     frames = 4 * slots if slots > 1 else 6
 
@@ -50,5 +53,5 @@ for slots in (1, 2, 3, 4, 6):
             cur.wait_stream(s)
     ms = timed(burst) / frames
     print(f"{view} shard {sh}: {slots} in flight: {ms:.3f} ms per frame = {single / ms:.2f}x  (efficiency {single / N / ms:.2f});  {pools[0].stats()}", flush=True)
-    for p in pools:
+    for p in pools + (orders or []):
         p.destroy()
