@@ -288,7 +288,11 @@ def main():
     # frame).  The camera is fixed here, so each rank times both on its own share (two bursts of 4 x slots frames each) and keeps the
     # faster; profiles/r05_sustained_chains.txt.  RRT_PATH_POLICY pins the path instead.
     path_tuning = None
-    if pipeline and fs.streams is not None and "RRT_PATH_POLICY" not in os.environ:
+    my_rays = w * sharding.shard_rows(h, R, rank, world)
+    auto_is_single = not pools or my_rays > rrt._lib.load().rrt_path_auto_max_rays()     # RRT_PATH_AUTO's own threshold
+    if pipeline and auto_is_single and "RRT_PATH_POLICY" not in os.environ:
+        path_tuning = {"all_ranks": "single kernel, media in line (a share of %d rays is above RRT_PATH_AUTO's three-pass threshold)" % my_rays}
+    elif pipeline and fs.streams is not None and "RRT_PATH_POLICY" not in os.environ:
         def burst_ms(policy):
             for p in prms:
                 p.path_policy = policy
