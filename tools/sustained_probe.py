@@ -11,7 +11,7 @@ VIEWS = {"default": ((0.0, 10.0, -60.0), 0.0, -10.0, 1.0), "skimmer": ((4.2, 0.6
          "key1": ((15.0, 3.0, -30.0), -26.6, -5.1, 6.0), "grazing": ((35.0, 0.8, 10.0), -106.0, -1.2, 12.0)}
 view = sys.argv[1] if len(sys.argv) > 1 else "skimmer"
 sh = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-W, H, R, N = 3840, 2160, 16, 8
+W, H, R, N = 3840, 2160, 16, int(os.environ.get("RRT_N", "8"))
 pos, yaw, pitch, t = VIEWS[view]
 cam = rrt.CameraState.from_angles(pos, yaw, pitch)
 tex = rrt.SkyTexture(synthetic_sky()); fx = rrt.CameraEffects(); nt = rrt.NoiseTable(32.0)
