@@ -10,22 +10,23 @@
  * static launch would have given them, which is the right order where costs tie (sky tiles) -- hipcub's ties came out in
  * tile-index order, top row first.
  *
- * How: LSD radix sort, two passes of 8 bits, THREE launches: histogram, scatter, scatter.  The problem is small (0.5 MB of
+ * How: LSD radix sort, two passes of 8 bits, FOUR short launches: histogram, scatter, histogram, scatter.  The problem is small (0.5 MB of
  * keys at 4K) and entirely latency-bound, so the design minimises dependent memory round trips and kernel boundaries rather
  * than maximising parallelism:
- *   - few fat blocks: 256 threads x 8 keys = 2 048 keys per block (64 blocks at 4K), all keys of a thread loaded in one
- *     batch and kept in registers for both the counting and the scattering phase of the kernel (a lone wavefront retires an
- *     instruction every ~10 clocks, so the instruction count per wave is the time: 16 keys per thread took 36 us per scatter,
- *     1 024-key blocks with a scan kernel in between 46 us; profiles/r05_tile_sort_timing.txt);
+ *   - few fat blocks: 2 048 keys per block (64 blocks at 4K), a thread's keys loaded in one batch and kept in registers for both
+ *     the counting and the scattering phase of the kernel; 1 024 threads x 2 keys -- a lone wavefront retires an instruction every
+ *     ~10 clocks, so a thread's serial instruction count is the time, and sixteen wavefronts on one CU overlap each other's
+ *     latencies (256 threads x 16 keys took 36 us per scatter, x 8 keys 20 us, 1 024-key blocks with a scan kernel in between 46 us;
+ *     profiles/r05_tile_sort_timing.txt);
  *   - no scan kernel: counters live as hist[block][digit]; a scatter block's thread d walks its digit's column once
- *     (n_blocks coalesced loads, issued together with the key loads), which gives it the digit's total and the count of the
- *     blocks before its own; an LDS scan of the 256 totals finishes the offsets;
- *   - pass 0 reads the costs through the static slot -> tile map and builds the NEXT pass's hist[][] with global atomics
- *     while it scatters (the destination of a key says which block will read it), so pass 1 needs no histogram launch;
+ *     (n_blocks coalesced loads shared by four threads per digit, issued together with the key loads), which gives it the digit's
+ *     total and the count of the blocks before its own; an LDS scan of the 256 totals finishes the offsets;
+ *   - pass 0 reads the costs through the static slot -> tile map; no global atomics anywhere (pass 0's scatter once built pass 1's
+ *     counters with them: the high byte of a cost is shared by most tiles of a frame, and same-address atomics made it 20 us);
  *   - 64-wide wavefronts rank their lanes with ballots (eight ballots give every lane the mask of the lanes that hold the
- *     same digit; the popcount below the lane is its rank); the four wavefronts of a block take consecutive quarters of its
+ *     same digit; the popcount below the lane is its rank); the sixteen wavefronts of a block take consecutive sixteenths of its
  *     chunk, LDS holds their per-digit write cursors.
- * No spin-waits, no inter-block communication other than kernel boundaries and those atomics.
+ * No spin-waits, no inter-block communication other than kernel boundaries.
  */
 #ifndef RRT_TILE_SORT_H
 #define RRT_TILE_SORT_H
@@ -36,9 +37,15 @@
 namespace rrt_sort {
 namespace {                                   /* internal linkage: the library exports nothing of this */
 
-constexpr unsigned kThreads = 256;            /* four wavefronts per block */
-constexpr unsigned kItems = 8;                /* keys per thread and batch */
-constexpr unsigned kBatch = kThreads * kItems;   /* 2 048 keys */
+#ifndef RRT_SORT_THREADS
+#define RRT_SORT_THREADS 1024
+#endif
+constexpr unsigned kThreads = RRT_SORT_THREADS;  /* sixteen wavefronts per block (one CU's worth at 4 per SIMD) */
+constexpr unsigned kWaves = kThreads / 64u;
+constexpr unsigned kParts = kThreads / 256u;  /* threads per digit in the column walk */
+constexpr unsigned kBatch = 2048;             /* keys per block and batch */
+constexpr unsigned kItems = kBatch / kThreads;   /* keys per thread and batch: 2 */
+static_assert(kThreads % 256u == 0 && kThreads <= 1024u && kItems * kThreads == kBatch, "a block is 256 ... 1 024 threads over 2 048 keys");
 constexpr unsigned kMaxBlocks = 1024;         /* a scatter thread walks a column of n_blocks counters: bound it */
 
 /* batches per block: 1 unless n needs more than kMaxBlocks blocks (> 2 M wave tiles) */
@@ -70,11 +77,10 @@ struct Pass {
     const unsigned* vals_in;
     unsigned* keys_out;            /* pass 0 only */
     unsigned* vals_out;
-    unsigned* hist;                /* [n_blocks][256] counts of THIS pass */
-    unsigned* hist_next;           /* pass 0: the next pass's counts (zeroed by the histogram kernel, filled by the scatter) */
+    unsigned* hist;                /* [n_blocks][256] counts of THIS pass's input chunks */
     unsigned n, reps, n_blocks, grid_x, grid_y;
     unsigned long long inv_gx;     /* ceil(2^48 / grid_x) */
-    int shift, shift_next;
+    int shift;
 };
 
 /* element i of the pass's input; an index past the end reads as (key 0, tile 0) and is never written anywhere */
@@ -87,55 +93,61 @@ __device__ __forceinline__ void load_item(const Pass& p, unsigned i, unsigned& k
     }
 }
 
-/* pass 0 only: hist[block][d] = digit counts of the block's chunk; the next pass's row is zeroed */
-__global__ __launch_bounds__(kThreads) void histogram0(Pass p) {
+/* hist[block][d] = digit counts of the block's chunk of the pass's input.  (The first version let pass 0's scatter build pass 1's
+ * counters with global atomics, to save this launch: the next digit is the HIGH byte of a cost, a frame's tiles share a few of those,
+ * and the same-address atomics made that scatter 20 us where its twin takes 6; a 5 us kernel of its own is the cheaper way.) */
+template <int PASS>
+__global__ __launch_bounds__(kThreads) void histogram(Pass p) {
     __shared__ unsigned h[256];
-    h[threadIdx.x] = 0u;
+    if (threadIdx.x < 256u) h[threadIdx.x] = 0u;
     __syncthreads();
     const unsigned base = blockIdx.x * kBatch * p.reps;
     for (unsigned r = 0; r < p.reps; ++r) {
         unsigned key[kItems], val[kItems];
 #pragma unroll
-        for (unsigned k = 0; k < kItems; ++k) load_item<0>(p, base + r * kBatch + k * kThreads + threadIdx.x, key[k], val[k]);
+        for (unsigned k = 0; k < kItems; ++k) load_item<PASS>(p, base + r * kBatch + k * kThreads + threadIdx.x, key[k], val[k]);
 #pragma unroll
         for (unsigned k = 0; k < kItems; ++k)
             if (base + r * kBatch + k * kThreads + threadIdx.x < p.n) atomicAdd(&h[digit_of(key[k], p.shift)], 1u);
     }
     __syncthreads();
-    p.hist[blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];
-    p.hist_next[blockIdx.x * 256u + threadIdx.x] = 0u;
+    if (threadIdx.x < 256u) p.hist[blockIdx.x * 256u + threadIdx.x] = h[threadIdx.x];
 }
 
-/* Stable scatter of the block's chunk.  Wavefront w owns the w-th quarter of the chunk (consecutive keys), 64 keys per
+/* Stable scatter of the block's chunk.  Wavefront w owns the w-th sixteenth of the chunk (consecutive keys), 64 keys per
  * step in order; a key's place = (keys with a smaller digit anywhere) + (same digit in earlier blocks) + (same digit in
- * earlier wavefronts of this block) + (same digit earlier in this wavefront's quarter). */
+ * earlier wavefronts of this block) + (same digit earlier in this wavefront's share).
+ * 1 024 threads x 2 keys (round 5, second version; the first had 256 x 8 and took 20 us): the serial part of a thread -- the
+ * ranking loop and its share of the column walk -- is a quarter as long, and the sixteen wavefronts of the block overlap each
+ * other's latencies on the CU's four SIMDs. */
 template <int PASS>
 __global__ __launch_bounds__(kThreads) void scatter(Pass p) {
-    __shared__ unsigned cur[4][256];
+    __shared__ unsigned cur[kWaves][256];
+    __shared__ unsigned part_tot[kParts][256], part_bef[kParts][256];
     __shared__ unsigned wave_tot[4];
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned quarter = kItems * 64u * p.reps;                     /* keys per wavefront */
-    const unsigned w_base = blockIdx.x * kBatch * p.reps + wave * quarter;
+    const unsigned share = kItems * 64u * p.reps;                       /* keys per wavefront */
+    const unsigned w_base = blockIdx.x * kBatch * p.reps + wave * share;
     /* the keys of the first batch (the only one unless the frame has > 2 M wave tiles): loads in flight ... */
     unsigned key[kItems], val[kItems];
 #pragma unroll
     for (unsigned k = 0; k < kItems; ++k) load_item<PASS>(p, w_base + k * 64u + lane, key[k], val[k]);
-    /* ... together with digit d's column of the block histograms: the digit's total and what the earlier blocks hold */
-    unsigned total = 0u, before = 0u;
+    /* ... together with digit d's column of the block histograms (the digit's total and what the earlier blocks hold), kParts
+     * threads per digit, each every kParts-th block: the 64 blocks of a 4K frame are ONE round trip of 16 loads per thread */
     {
-        const unsigned d = threadIdx.x;
-        /* 32 loads in flight per round trip (the 64 blocks of a 4K frame: two round trips; with 8 per batch this walk was ~8 us of
-         * a 20 us kernel) */
-        constexpr unsigned kWalk = 32;
-        for (unsigned b0 = 0; b0 < p.n_blocks; b0 += kWalk) {
+        const unsigned d = threadIdx.x & 255u, part = threadIdx.x >> 8;
+        unsigned total = 0u, before = 0u;
+        constexpr unsigned kWalk = 16;
+        for (unsigned b0 = part; b0 < p.n_blocks; b0 += kWalk * kParts) {
             unsigned v[kWalk];
 #pragma unroll
-            for (unsigned j = 0; j < kWalk; ++j) v[j] = b0 + j < p.n_blocks ? p.hist[(b0 + j) * 256u + d] : 0u;
+            for (unsigned j = 0; j < kWalk; ++j) v[j] = b0 + j * kParts < p.n_blocks ? p.hist[(b0 + j * kParts) * 256u + d] : 0u;
 #pragma unroll
-            for (unsigned j = 0; j < kWalk; ++j) { total += v[j]; before += b0 + j < blockIdx.x ? v[j] : 0u; }
+            for (unsigned j = 0; j < kWalk; ++j) { total += v[j]; before += b0 + j * kParts < blockIdx.x ? v[j] : 0u; }
         }
+        part_tot[part][d] = total; part_bef[part][d] = before;
     }
-    for (unsigned k = threadIdx.x; k < 4u * 256u; k += kThreads) (&cur[0][0])[k] = 0u;
+    for (unsigned k = threadIdx.x; k < kWaves * 256u; k += kThreads) (&cur[0][0])[k] = 0u;
     __syncthreads();
     /* per-wave digit counts of this block's chunk */
     for (unsigned r = 0; r < p.reps; ++r) {
@@ -147,22 +159,28 @@ __global__ __launch_bounds__(kThreads) void scatter(Pass p) {
         for (unsigned k = 0; k < kItems; ++k)
             if (w_base + r * kItems * 64u + k * 64u + lane < p.n) atomicAdd(&cur[wave][digit_of(key[k], p.shift)], 1u);
     }
-    /* exclusive scan of the 256 digit totals (thread d holds total[d]) */
-    unsigned incl = total;
+    /* threads 0 .. 255 (wavefronts 0 .. 3): thread d holds digit d's total and the earlier blocks' count; exclusive scan of the
+     * 256 totals */
+    unsigned total = 0u, before = 0u, incl = 0u;
+    if (threadIdx.x < 256u) {
 #pragma unroll
-    for (unsigned o = 1; o < 64u; o <<= 1) {
-        const unsigned up = (unsigned)__shfl_up((int)incl, o);
-        if (lane >= o) incl += up;
+        for (unsigned q = 0; q < kParts; ++q) { total += part_tot[q][threadIdx.x]; before += part_bef[q][threadIdx.x]; }
+        incl = total;
+#pragma unroll
+        for (unsigned o = 1; o < 64u; o <<= 1) {
+            const unsigned up = (unsigned)__shfl_up((int)incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63u) wave_tot[wave] = incl;
     }
-    if (lane == 63u) wave_tot[wave] = incl;
     __syncthreads();
-    {
+    if (threadIdx.x < 256u) {
         unsigned smaller = incl - total;
         for (unsigned w = 0; w < wave; ++w) smaller += wave_tot[w];
         const unsigned d = threadIdx.x;
         unsigned at = smaller + before;                                  /* where this block's keys of digit d start */
 #pragma unroll
-        for (unsigned w = 0; w < 4u; ++w) { const unsigned c = cur[w][d]; cur[w][d] = at; at += c; }
+        for (unsigned w = 0; w < kWaves; ++w) { const unsigned c = cur[w][d]; cur[w][d] = at; at += c; }
     }
     __syncthreads();
     for (unsigned r = 0; r < p.reps; ++r) {
@@ -183,13 +201,8 @@ __global__ __launch_bounds__(kThreads) void scatter(Pass p) {
             const unsigned long long below = peers & ((1ull << lane) - 1ull);
             if (valid) {
                 const unsigned pos = cur[wave][d] + (unsigned)__popcll(below);
-                if (PASS == 0) {
-                    p.keys_out[pos] = key[k];
-                    p.vals_out[pos] = val[k];
-                    atomicAdd(&p.hist_next[(pos / (kBatch * p.reps)) * 256u + digit_of(key[k], p.shift_next)], 1u);
-                } else {
-                    p.vals_out[pos] = val[k];
-                }
+                if (PASS == 0) p.keys_out[pos] = key[k];
+                p.vals_out[pos] = val[k];
             }
             __builtin_amdgcn_wave_barrier();                    /* every lane has read its cursor before the leaders move them */
             if (valid && below == 0ull) cur[wave][d] += (unsigned)__popcll(peers);
@@ -206,15 +219,13 @@ inline hipError_t enqueue(const unsigned* d_cost, unsigned* d_keys_tmp, unsigned
     Pass p{};
     p.n = (unsigned)n; p.reps = reps_for(n); p.n_blocks = blocks_for(n); p.grid_x = grid_x; p.grid_y = grid_y;
     p.inv_gx = ((1ull << 48) + grid_x - 1) / grid_x;
-    unsigned* hist0 = d_scratch;
-    unsigned* hist1 = d_scratch + (size_t)256 * kMaxBlocks;
-    p.cost = d_cost; p.keys_out = d_keys_tmp; p.vals_out = d_vals_tmp;
-    p.hist = hist0; p.hist_next = hist1; p.shift = lo_bit; p.shift_next = lo_bit + 8;
-    hipLaunchKernelGGL(histogram0, dim3(p.n_blocks), dim3(kThreads), 0, st, p);
+    p.cost = d_cost; p.keys_out = d_keys_tmp; p.vals_out = d_vals_tmp; p.hist = d_scratch; p.shift = lo_bit;
+    hipLaunchKernelGGL(histogram<0>, dim3(p.n_blocks), dim3(kThreads), 0, st, p);
     hipLaunchKernelGGL(scatter<0>, dim3(p.n_blocks), dim3(kThreads), 0, st, p);
     Pass q = p;
     q.cost = nullptr; q.keys_in = d_keys_tmp; q.vals_in = d_vals_tmp; q.keys_out = nullptr; q.vals_out = d_perm_out;
-    q.hist = hist1; q.hist_next = nullptr; q.shift = lo_bit + 8; q.shift_next = 0;
+    q.hist = d_scratch + (size_t)256 * kMaxBlocks; q.shift = lo_bit + 8;
+    hipLaunchKernelGGL(histogram<1>, dim3(p.n_blocks), dim3(kThreads), 0, st, q);
     hipLaunchKernelGGL(scatter<1>, dim3(p.n_blocks), dim3(kThreads), 0, st, q);
     return hipGetLastError();
 }

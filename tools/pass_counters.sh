@@ -14,7 +14,7 @@ python3 - "$view" "$path" "$D" "$R/gpurun_out/passc_${view}_${path}.json" <<'PY'
 import csv, glob, json, re, sys
 view, path, D, out = sys.argv[1:5]
 def short(n):
-    m = re.search(r"(raymarch_pixels|march_defer|eval_sample_rows|composite_and_shade|pool_next_round|zero_words|probe_costs|probe_to_tiles|histogram0|scan_counters|scatter|build_noise_table)", n)
+    m = re.search(r"(raymarch_pixels|march_defer|eval_sample_rows|composite_and_shade|pool_next_round|zero_words|probe_costs|probe_to_tiles|histogram|scan_counters|scatter|build_noise_table)", n)
     return m.group(1) if m else None
 res = {"view": view, "path": path, "kernels": {}}
 kt = glob.glob(f"{D}/trace/**/*kernel_trace.csv", recursive=True)

@@ -15,7 +15,7 @@ for f in sorted(glob.glob("gpurun_out/passc_*.json")):
     key = f"{d['view']}/{d['path']}"
     ks = {}
     for k, v in d["kernels"].items():
-        if v.get("total_ms", 0) / max(d.get("frames_traced", 4), 1) < 0.01 and k not in ("scatter", "histogram0"):
+        if v.get("total_ms", 0) / max(d.get("frames_traced", 4), 1) < 0.01 and k not in ("scatter", "histogram"):
             continue
         ks[k] = {"ms_per_frame": round(v.get("total_ms", 0) / d.get("frames_traced", 4), 4),
                  "launches_per_frame": round(v.get("calls", 0) / d.get("frames_traced", 4), 2),
