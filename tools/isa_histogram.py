@@ -142,6 +142,11 @@ def analyse(src, name, pretty):
         sections.append(("VACUUM path of the march loop (every lane at r >= 30: one RK4 step, h = 0.3 folded, no zone tests)", vacuum))
     sections.append(("generic path of the march loop (one RK4 step" + (", media blocks included" if len(loop) > 60 else "") + ")", straight))
     sections.append(("blocks of the loop off those paths (guarded fall-backs: rejected seeds, a stage radius < 1; lanes leaving)", sideb))
+    if os.environ.get("RRT_ISA_DUMP") and os.environ["RRT_ISA_DUMP"] in pretty:      # the vacuum path's listing (or the generic one)
+        for b in (vacuum or straight):
+            print("      " + b["label"])
+            for t in b["ins"]:
+                print("         " + t)
     for title, bl in sections:
         ins = [t.split()[0] for b in bl for t in b["ins"]]
         cls = collections.Counter(classify(o) for o in ins)
