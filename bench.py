@@ -560,6 +560,44 @@ def main():
             heavy["noise_table_cost_ordered"]["note"] = ("rrt_params.tile_order: wave tiles dispatched longest-first, costs measured by the previous "
                                                          "launch (the sort behind every frame is inside the time); same bytes")
 
+    # Informational fourth leg (single GPU): what 8 ranks would do with THIS frame, projected on this GPU -- every rank's share (16-row
+    # tiles t mod 8) rendered alone the way a rank of `bench.py --gpus 8` renders it (three frames in flight on three streams; the
+    # three-pass path in one chain per launch, and the plain single kernel), sustained ms per frame; the slowest shard bounds the frame
+    # rate.  Gather / assemble are not in it (4.15 MB per rank on another stream).  A projection, not a measurement of 8 GPUs.
+    projection = None
+    if world == 1 and not args.no_heavy and ntab and h >= 8 * R:
+        NP, slots = 8, 3
+        p_pools = [rrt.Workspace(2 << 30) for _ in range(slots)]
+        p_streams = [torch.cuda.Stream(dev) for _ in range(slots)]
+        p_bufs = [torch.zeros(sharding.shard_rows(h, R, 0, NP) * w * 4, dtype=torch.uint8, device=dev) for _ in range(slots)]
+
+        def sustained(shard, policy):
+            prm3 = [rrt.RenderParams(spin=args.spin, volumetrics=1, noise_table=ntab.id, workspace=p_pools[j].id, path_policy=policy, pass_chains=1)
+                    for j in range(slots)]
+            best = 1e9
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for k in range(4 * slots):
+                    rrt.launch_raymarch_tiles(p_bufs[k % slots], w, h, R, shard, NP, 1.0, cam, tex, fx, prm3[k % slots], stream=p_streams[k % slots])
+                torch.cuda.synchronize(dev)
+                best = min(best, (time.perf_counter() - t1) * 1e3 / (4 * slots))
+            return best
+        tp = [sustained(sh, 2) for sh in range(NP)]
+        il = [sustained(sh, 1) for sh in range(NP)]
+        best_rank = [min(a_, b_) for a_, b_ in zip(tp, il)]
+        one = dt / args.steps * 1e3
+        projection = {"ranks": NP, "frames_in_flight": slots, "tile_rows": R, "single_gpu_ms": round(one, 3),
+                      "three_pass_one_chain": {"per_shard_ms": [round(v, 3) for v in tp], "max_ms": round(max(tp), 3), "x_of_single_gpu": round(one / max(tp), 2)},
+                      "single_kernel": {"per_shard_ms": [round(v, 3) for v in il], "max_ms": round(max(il), 3), "x_of_single_gpu": round(one / max(il), 2)},
+                      "faster_path_per_rank": {"max_ms": round(max(best_rank), 3), "x_of_single_gpu": round(one / max(best_rank), 2)},
+                      "note": "PROJECTION on one GPU, not a multi-GPU measurement: each of the 8 shares of this frame alone on this GPU, sustained with "
+                              "three frames in flight as a rank of `bench.py --gpus 8` keeps them (which also picks the faster path per rank at start-up); "
+                              "the slowest share bounds the frame rate; the RCCL gather (4.15 MB per rank) and the assemble kernel are not included"}
+        for pw in p_pools:
+            pw.destroy()
+        del p_bufs
+
     if rank == 0:
         rays = w * h
         ms_per_step = dt / args.steps * 1e3
@@ -666,6 +704,7 @@ def main():
             "cpu_baseline": cpu,
             "within_tolerance_mode": wtol,
             "headline_arithmetic_noise": arith_noise,
+            "projection_8_ranks": projection,
             "heavy_view": heavy,
         }
         if world > 1:

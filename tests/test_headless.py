@@ -259,6 +259,10 @@ def test_bench_line_contract():
     assert abs(rf["frac_at_held_clock"] - rf["achieved"] / (256 * 4 * 32 * rf["clock_ghz"] / 1e3)) < 2e-3
     hv = d["heavy_view"]
     assert hv["noise_table_first_frame_probe_ordered"]["ms_per_step"] > 0 and hv["noise_table_cost_ordered"]["ms_per_step"] > 0
+    # round 5: the 8-rank projection of this very frame travels with the single-GPU line (every share alone on this GPU, sustained)
+    pj = d["projection_8_ranks"]
+    assert pj["ranks"] == 8 and len(pj["three_pass_one_chain"]["per_shard_ms"]) == 8 and len(pj["single_kernel"]["per_shard_ms"]) == 8
+    assert pj["faster_path_per_rank"]["max_ms"] <= min(pj["three_pass_one_chain"]["max_ms"], pj["single_kernel"]["max_ms"]) and "PROJECTION" in pj["note"]
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]
     if cb["kind"] == "reference":       # oracle/_ref travelled with the tree: the reference's own kernel body was timed
