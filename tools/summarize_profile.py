@@ -1,25 +1,22 @@
 """dev tool: condense gpurun_out/prof_<tag>/ into profiles/<tag>_*.{csv,json} (run in the container)."""
 import csv, glob, json, os, sys
-tag = sys.argv[1]
-src = f"gpurun_out/prof_{tag}"
-os.makedirs("profiles", exist_ok=True)
-out = {"tag": tag}
-ks = glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True)
-if ks:
-    rows = list(csv.DictReader(open(ks[0])))
-    with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
-        f.write(open(ks[0]).read())
-    # kernel names end in <SPIN, MEDIA, DEBUG, ARITH>: the headline is the production instantiation in strict arithmetic
-    # (", false, 0>(") WITH THE MEDIA TEMPLATE THE TIMED LOOP USES -- the highest one present (2 / 3: noise tables; bench.py's
-    # headline_arithmetic_noise leg launches MEDIA 1 at the same grid, and rounds 5 b-f averaged the two: the committed
-    # r05_b..f summaries quote 117 MB fetched and 37.6 ms where the table kernel alone fetches 226 MB and takes 37.4 ms; found and
-    # fixed at the end of round 5, r05_f re-summarised from the same rocprofv3 output).  ARITH 2 = RRT_ARITH_FMAD, 1 = RRT_ARITH_FAST;
-    # the debug instantiations (conditioning account) are skipped
+
+
+def make_kind(names):
+    """kernel name -> "kernel" | "fast_mode_kernel" | "fmad_mode_kernel" | "arithmetic_noise_kernel" | None, for the instantiations in
+    `names`.  Kernel names end in <SPIN, MEDIA, DEBUG, ARITH>: the headline is the production instantiation in strict arithmetic
+    (", false, 0>(") WITH THE MEDIA TEMPLATE THE TIMED LOOP USES -- the highest one present (2 / 3: noise tables; bench.py's
+    headline_arithmetic_noise leg launches MEDIA 1 at the same grid, and round 5's b-f summaries averaged the two: they quote 117 MB
+    fetched and 37.6 ms where the table kernel alone fetches 226 MB and takes 37.4 ms; found and fixed at the end of round 5, r05_f
+    re-summarised from the same rocprofv3 output; tests/test_tools.py pins it).  ARITH 2 = RRT_ARITH_FMAD, 1 = RRT_ARITH_FAST; the debug
+    instantiations (conditioning account) are skipped."""
     def media_of(name):
         return int(name.split("raymarch_pixels<")[1].split(",")[1])
+
     def production(name):
         return "raymarch_pixels<" in name and ", false, " in name
-    top_media = max([media_of(r["Name"]) for r in rows if production(r["Name"])], default=0)
+    top_media = max([media_of(n) for n in names if production(n)], default=0)
+
     def kind(name):
         if not production(name):
             return None
@@ -27,55 +24,72 @@ if ks:
         if media_of(name) != top_media:
             return "arithmetic_noise_kernel" if k == "kernel" and media_of(name) == 1 else None
         return k
-    for r in rows:
-        key = kind(r["Name"])
-        if key:
-            out[key] = r["Name"]; out[key + "_calls"] = int(r["Calls"]); out[key + "_avg_ms"] = float(r["AverageNs"]) / 1e6
-kt = glob.glob(f"{src}/trace/**/*kernel_trace.csv", recursive=True)
-if kt:
-    # average over the full-frame dispatches only (bench.py also makes one tiny untimed pre-warm launch)
-    rows = [r for r in csv.DictReader(open(kt[0])) if kind(r["Kernel_Name"])]
-    for key in ("kernel", "fast_mode_kernel", "fmad_mode_kernel", "arithmetic_noise_kernel"):
-        sel = [r for r in rows if kind(r["Kernel_Name"]) == key]
-        if sel:
-            big = max(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) for r in sel)
-            d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in sel
-                 if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == big]
-            out[key + "_calls"] = len(d); out[key + "_avg_ms"] = sum(d) / len(d)
-            out[key] = [r["Kernel_Name"] for r in sel if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == big][0]
-    strict = [r for r in rows if kind(r["Kernel_Name"]) == "kernel"]
-    if strict:
-        r = max(strict, key=lambda r: int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]))      # the full-frame launch
-        # rocprofv3's VGPR_Count column reads 48 for this 95-register kernel (half the 96 allocated); the compiler's
-        # own figure is in profiles/*_isa_march_loops.txt
-        out["rocprof_vgpr_count_field"] = int(r["VGPR_Count"]); out["sgpr"] = int(r["SGPR_Count"]); out["lds"] = int(r["LDS_Block_Size"])
-        out["scratch"] = int(r["Scratch_Size"]); out["grid"] = [int(r["Grid_Size_X"]), int(r["Grid_Size_Y"])]
-for name in ("fetch", "write", "sq"):
-    cs = glob.glob(f"{src}/pmc_{name}/**/*counter_collection.csv", recursive=True)
-    if not cs:
-        continue
-    acc = {}
-    n = {}
-    allrows = [r for r in csv.DictReader(open(cs[0])) if kind(r["Kernel_Name"]) == "kernel"]
-    big = max((int(r["Grid_Size"]) for r in allrows), default=0)
-    for r in allrows:
-        if int(r["Grid_Size"]) != big:      # skip bench.py's tiny pre-warm launch
+    return kind
+
+
+def main(tag):
+    src = f"gpurun_out/prof_{tag}"
+    os.makedirs("profiles", exist_ok=True)
+    out = {"tag": tag}
+    ks = glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True)
+    if ks:
+        rows = list(csv.DictReader(open(ks[0])))
+        with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
+            f.write(open(ks[0]).read())
+        kind = make_kind([r["Name"] for r in rows])
+        for r in rows:
+            key = kind(r["Name"])
+            if key:
+                out[key] = r["Name"]; out[key + "_calls"] = int(r["Calls"]); out[key + "_avg_ms"] = float(r["AverageNs"]) / 1e6
+    kt = glob.glob(f"{src}/trace/**/*kernel_trace.csv", recursive=True)
+    if kt:
+        # average over the full-frame dispatches only (bench.py also makes one tiny untimed pre-warm launch)
+        rows = [r for r in csv.DictReader(open(kt[0])) if kind(r["Kernel_Name"])]
+        for key in ("kernel", "fast_mode_kernel", "fmad_mode_kernel", "arithmetic_noise_kernel"):
+            sel = [r for r in rows if kind(r["Kernel_Name"]) == key]
+            if sel:
+                big = max(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) for r in sel)
+                d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in sel
+                     if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == big]
+                out[key + "_calls"] = len(d); out[key + "_avg_ms"] = sum(d) / len(d)
+                out[key] = [r["Kernel_Name"] for r in sel if int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) == big][0]
+        strict = [r for r in rows if kind(r["Kernel_Name"]) == "kernel"]
+        if strict:
+            r = max(strict, key=lambda r: int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]))      # the full-frame launch
+            # rocprofv3's VGPR_Count column reads 48 for this 95-register kernel (half the 96 allocated); the compiler's
+            # own figure is in profiles/*_isa_march_loops.txt
+            out["rocprof_vgpr_count_field"] = int(r["VGPR_Count"]); out["sgpr"] = int(r["SGPR_Count"]); out["lds"] = int(r["LDS_Block_Size"])
+            out["scratch"] = int(r["Scratch_Size"]); out["grid"] = [int(r["Grid_Size_X"]), int(r["Grid_Size_Y"])]
+    for name in ("fetch", "write", "sq"):
+        cs = glob.glob(f"{src}/pmc_{name}/**/*counter_collection.csv", recursive=True)
+        if not cs:
             continue
-        acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-        n[r["Counter_Name"]] = n.get(r["Counter_Name"], 0) + 1
-    for k in acc:
-        out[k + "_per_launch"] = acc[k] / n[k]
-if "FETCH_SIZE_per_launch" in out and "WRITE_SIZE_per_launch" in out:
-    # HBM bytes per launch of the dominant kernel: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports
-    # half the bytes of wide reads (MI355X_MICROARCH.md, HBM) -> doubled (an upper bound for this kernel's narrow
-    # gather reads); the two counters come from separate --pmc passes.  Keyed on the kernel sources so that
-    # bench.py never reports it for another build.
-    sys.path.insert(0, ".")
-    import bench
-    traffic = {"workload": "3840x2160_a0.9_vol", "source_hash": bench.source_hash(),
-               "bytes_per_launch": (2 * out["FETCH_SIZE_per_launch"] + out["WRITE_SIZE_per_launch"]) * 1024,
-               "from": f"profiles/{tag}_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes",
-               "fetch_kb": out["FETCH_SIZE_per_launch"], "write_kb": out["WRITE_SIZE_per_launch"]}
-    json.dump(traffic, open("profiles/hbm_traffic.json", "w"), indent=1)
-json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
-print(json.dumps(out, indent=1))
+        acc = {}
+        n = {}
+        allrows = [r for r in csv.DictReader(open(cs[0])) if kind(r["Kernel_Name"]) == "kernel"]
+        big = max((int(r["Grid_Size"]) for r in allrows), default=0)
+        for r in allrows:
+            if int(r["Grid_Size"]) != big:      # skip bench.py's tiny pre-warm launch
+                continue
+            acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            n[r["Counter_Name"]] = n.get(r["Counter_Name"], 0) + 1
+        for k in acc:
+            out[k + "_per_launch"] = acc[k] / n[k]
+    if "FETCH_SIZE_per_launch" in out and "WRITE_SIZE_per_launch" in out:
+        # HBM bytes per launch of the dominant kernel: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports
+        # half the bytes of wide reads (MI355X_MICROARCH.md, HBM) -> doubled (an upper bound for this kernel's narrow
+        # gather reads); the two counters come from separate --pmc passes.  Keyed on the kernel sources so that
+        # bench.py never reports it for another build.
+        sys.path.insert(0, ".")
+        import bench
+        traffic = {"workload": "3840x2160_a0.9_vol", "source_hash": bench.source_hash(),
+                   "bytes_per_launch": (2 * out["FETCH_SIZE_per_launch"] + out["WRITE_SIZE_per_launch"]) * 1024,
+                   "from": f"profiles/{tag}_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes",
+                   "fetch_kb": out["FETCH_SIZE_per_launch"], "write_kb": out["WRITE_SIZE_per_launch"]}
+        json.dump(traffic, open("profiles/hbm_traffic.json", "w"), indent=1)
+    json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
