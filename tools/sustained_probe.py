@@ -40,7 +40,7 @@ for slots in (1, 2, 3, 4, 6, 8):
     orders = [rrt.TileOrder() for _ in range(slots)] if os.environ.get("RRT_ORDER", "0") == "1" else None
     prms = [rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=pools[j].id, path_policy=int(os.environ.get("RRT_POLICY", "2")),
                              tile_order=orders[j].id if orders else 0,
-                             pass_chains=int(os.environ.get("RRT_CHAINS", "0"))) for j in range(slots)]
+                             pass_chains=int(os.environ.get("RRT_CHAINS", "0")), pool_rounds=int(os.environ.get("RRT_ROUNDS", "0"))) for j in range(slots)]
     frames = 4 * slots if slots > 1 else 6
 
     def burst():
