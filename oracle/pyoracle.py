@@ -16,6 +16,7 @@ REF_UNITS_PATH = os.path.join(HERE, "_ref", "libref_units.so")
 REF_CAMERA_PATH = os.path.join(HERE, "_ref", "libref_camera.so")
 REF_FRAMES_PATH = os.path.join(HERE, "_ref", "libref_frames.so")
 REF_STB_PATH = os.path.join(HERE, "_ref", "libref_stb.so")
+REF_FRAMES_FMA_PATH = os.path.join(HERE, "_ref", "libref_frames_fma.so")     # the same kernel text under -ffp-contract=fast -mfma
 
 MATH_LIBM = 0
 MATH_PORTABLE = 1
@@ -52,7 +53,7 @@ class Diag(C.Structure):
 
 def build(ref=False, quiet=True):
     """(Re)build the oracle; `ref=True` also builds oracle/_ref when /root/reference exists."""
-    targets = ["all"] + (["ref"] if ref else [])
+    targets = ["all"] + (["ref", "ref-fma"] if ref else [])
     subprocess.run(["make", "-C", HERE] + targets, check=True,
                    stdout=subprocess.DEVNULL if quiet else None)
 
@@ -309,13 +310,18 @@ def ref_frames_available():
     return os.path.exists(REF_FRAMES_PATH)
 
 
-def ref_render(cam_arr, fx, spin, volumetrics, time, width, height, sky, frac_bits=8, n_threads=0, stride=(1, 1)):
+def ref_frames_fma_available():
+    return os.path.exists(REF_FRAMES_FMA_PATH)
+
+
+def ref_render(cam_arr, fx, spin, volumetrics, time, width, height, sky, frac_bits=8, n_threads=0, stride=(1, 1), fma=False):
     """One frame from the REFERENCE's own raymarch_kernel body (oracle/_ref/libref_frames.so, compiled in the
     build container from /root/reference; oracle/ref_frames.cpp).  `cam_arr` is the 4x3 basis, `fx` an Effects;
     `stride` = (sx, sy) renders every sx-th column of every sy-th row only.
+    `fma=True`: the same kernel text compiled with floating-point contraction (oracle/Makefile ref-fma).
     Returns {"rgba8": (h, w, 4) uint8 bottom-up, "steps": (h*w,) int32 top-down}."""
     lib()                                   # librrt_oracle.so (the sampler) must be loaded first
-    dll = C.CDLL(REF_FRAMES_PATH)
+    dll = C.CDLL(REF_FRAMES_FMA_PATH if fma else REF_FRAMES_PATH)
     dll.ref_render_strided.restype = _i
     cam12 = _fa(np.asarray(cam_arr).reshape(12))
     flags = np.array([fx.use_bloom, fx.use_vignette, fx.use_ca, fx.use_lens], np.int32)

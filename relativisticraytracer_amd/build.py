@@ -98,8 +98,9 @@ def build_lib(force=False, extra_flags=(), verbose=False):
 def build_variant(name, extra_flags=()):
     """dev builds for A/B timing: lib/variants/<name>.so with extra hipcc flags (tools/ab_views.py)."""
     vdir = os.path.join(LIBDIR, "variants")
-    os.makedirs(vdir, exist_ok=True)
-    host_objs = host_objects(vdir)
+    hdir = os.path.join(vdir, name + "_host")          # its own directory: variant builds may run side by side
+    os.makedirs(hdir, exist_ok=True)
+    host_objs = host_objects(hdir)
     obj = os.path.join(vdir, name + ".o")
     base = [f for f in HIPCC_FLAGS if f != "-shared"]
     for d in [f[len("--drop="):] for f in extra_flags if f.startswith("--drop=")]:      # --drop=<flag>: build WITHOUT a shipped flag
@@ -109,12 +110,13 @@ def build_variant(name, extra_flags=()):
         else:
             del base[i]
     extra_flags = [f for f in extra_flags if not f.startswith("--drop=")]
-    subprocess.run([hipcc_path()] + base + list(extra_flags) + ["-c"] + SOURCES + ["-o", obj], check=True, cwd=vdir)
+    subprocess.run([hipcc_path()] + base + list(extra_flags) + ["-c"] + SOURCES + ["-o", obj], check=True, cwd=hdir)
     out = os.path.join(vdir, name + ".so")
     subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", obj] + host_objs + ["-o", out],
                    check=True, cwd=vdir)
     for o in [obj] + host_objs:
         os.remove(o)
+    os.rmdir(hdir)
     return out
 
 

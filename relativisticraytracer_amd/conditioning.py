@@ -12,10 +12,15 @@ arithmetic, and can be measured with it: render the strict frame again with ever
     ill    pixels where some N_j is outside tol(S) = rel |S| + floor in some channel, or takes another number of steps
     F      the mode's frame; DEVIANT pixels: outside tol(S), another step count, or a byte off by more than one LSB
 
-`account()` adds nudged frames until every deviant pixel of every mode is ill (or the budget is spent) and returns the masks
-and the counts.  Everything runs on the GPU through the C ABI; torch is the device-memory plumbing.
+`account()` always renders a FIXED set of nudged frames (FIXED_FRAMES, the same K / seed list for every view) and reports what
+that set leaves uncovered; it then adds frames until every deviant pixel of every mode is ill (or the budget is spent) and returns
+the masks and the counts.  The ill set only grows with the frames, so the "0 not ill" result depends on the stopping rule: the
+bars that do not (outlier counts at the measured class, under what ONE 4-ulp nudge does to the strict frame) are the guard, and
+tests/test_gpu_tolerance.py asserts them.  Everything runs on the GPU through the C ABI; torch is the device-memory plumbing.
 """
 KS = (1, 2, 4, 8, 16)
+FIXED_FRAMES = 20                        # the fixed nudge set: always rendered, the same (K, seed) list for every view; what it leaves
+                                         # uncovered is reported (stats["fixed_set"]) next to the adaptive account (ADVICE r05)
 REL_TOL, ABS_FLOOR = 1e-4, 1e-5          # north_star: "within 1e-4 relative per channel"; floor for near-black pixels
 
 
@@ -48,6 +53,7 @@ def account(tex, w, h, cam, t, modes, fx=None, min_frames=10, budget=120, **prm_
     ill = torch.zeros(h, w, dtype=torch.bool, device="cuda")
     single = {}                  # K -> pixels ONE nudged strict frame moves (the first frame of each K)
     frames = 0
+    fixed = None                 # the account after the FIXED set: FIXED_FRAMES frames (K, seed) = (KS[j % 5], 977 K + j), the same for every view
     while frames < budget:
         K = KS[frames % len(KS)]
         N, n_steps, _ = _frame(rrt, tex, fx, w, h, cam, t, dict(prm_kw, nudge_ulps=K, nudge_seed=977 * K + frames))
@@ -55,9 +61,12 @@ def account(tex, w, h, cam, t, modes, fx=None, min_frames=10, budget=120, **prm_
         single.setdefault(K, int(moved.sum()))
         ill |= moved
         frames += 1
-        if frames >= min_frames and not bool((deviant & ~ill).any()):
+        if frames == min(FIXED_FRAMES, budget):
+            fixed = {"frames": frames, "ill": int(ill.sum()), "deviant_not_ill": int((deviant & ~ill).sum()), "deviant": int(deviant.sum())}
+        if frames >= max(min_frames, min(FIXED_FRAMES, budget)) and not bool((deviant & ~ill).any()):
             break
-    stats = {"pixels": w * h, "nudged_frames": frames, "ill": int(ill.sum()), "single_nudge_moves": single,
+    stats = {"pixels": w * h, "nudged_frames": frames, "budget": budget, "ill": int(ill.sum()), "single_nudge_moves": single,
+             "fixed_set": fixed,
              "tolerance": f"{REL_TOL:g} |x| + {ABS_FLOOR:g} per channel, float RGB before the u8 cast"}
     for m in modes:
         d8 = (res[m]["rgba8"][..., :3].int() - s8[..., :3].int()).abs()

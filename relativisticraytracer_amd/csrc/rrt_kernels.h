@@ -314,6 +314,15 @@ __device__ __forceinline__ void zone_step(bool near_bh, bool in_disk, float& h, 
 #ifndef RRT_VACUUM_PATH
 #define RRT_VACUUM_PATH 1
 #endif
+/* RRT_VAC_INNER = N > 0: the single kernel's vacuum steps run in a loop of their own, unrolled N times (march_inline);
+ * 0: round 3-5's flat loop. */
+#ifndef RRT_VAC_INNER
+#define RRT_VAC_INNER 2
+#endif
+/* the escape test's dot product behind a wave-uniform `some lane is beyond r = 250` (1), or evaluated on every step (0) */
+#ifndef RRT_VAC_ESC_BRANCH
+#define RRT_VAC_ESC_BRANCH 1
+#endif
 #ifndef RRT_HORIZON_IN_GENERIC
 #define RRT_HORIZON_IN_GENERIC 0
 #endif
@@ -358,7 +367,10 @@ __device__ __forceinline__ void march_inline_v1(const FrameArgs& a, v3& p, v3& v
     i = steps;
 }
 
-template <bool SPIN, int MEDIA, int ARITH>
+/* UK: every lane of the wave enters at the same step `i` (the single kernel: 0), so the step counter is one number per wave;
+ * the loop says so once per outer iteration (v_readfirstlane), which keeps the counter and the vacuum loop's exit code in
+ * scalar registers whatever the compiler makes of the merged exits of the outer loop. */
+template <bool SPIN, int MEDIA, int ARITH, bool UK = false>
 __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel, Radiance& acc, bool& hit, int& i,
                                              unsigned* oob) {
     constexpr bool FMA = ARITH == kArithFmad;           /* the lean loop with fused multiply-adds (rrt_device.h: integrate_rk4_lean) */
@@ -368,6 +380,73 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
         int steps = i > a.max_steps ? i : a.max_steps;  /* if the loop runs out */
         float ys = 0.0f, hs = 0.0f;                     /* (1/r, 1/(2r)) estimate for the next loop-top radius; 0: none yet */
         float hcp = 0.0f;                               /* 1/(2r) at the previous vacuum step's stage 3 (seed extrapolation) */
+#if RRT_VAC_INNER
+        /* Round 6: the vacuum steps of a wavefront in a loop of their own, every exit of which is wave-uniform.  In the flat
+         * loop (#else) the vacuum and the generic path meet before the back edge, and the step that is taken nine times in
+         * ten paid the register copies of that meeting (FMAD: 14 v_mov on 221 arithmetic instructions).  Here the
+         * loop-carried state has one producer; with the body written out twice a step can write its results into the
+         * registers of the state before last, which the escape test (pre-step position, post-step velocity:
+         * raymarcher.cu:120) has released by then.  A lane that escapes does not leave by itself (a divergent exit would make
+         * the step counter a per-lane value): the wave leaves, the escaped lanes end their march, the others re-enter. */
+        int k = i;
+        while (k < a.max_steps) {
+            if (UK) k = __builtin_amdgcn_readfirstlane(k);
+            v3 rel_p = p;                               /* p - MASS_POS, MASS_POS = 0 */
+            float r2 = FMA ? dot_fma(rel_p, rel_p) : dot(rel_p, rel_p);
+            float r, y, hy;
+            bool rejected = sqrt_seeded_yh<1>(r2, ys, hs, r, y, hy);
+            /* wave-uniform: every live lane holds an accepted radius >= kVacuumR (two compares, scalar logic) */
+            unsigned long long rej_mask = __builtin_amdgcn_ballot_w64(rejected);
+            if (RRT_VACUUM_PATH && (rej_mask | __builtin_amdgcn_ballot_w64(!(r >= kVacuumR))) == 0ull) {
+                bool escaped;
+                int why;                                /* 1: a lane escaped; 2: out of steps; 3: a lane needs the generic step */
+#define RRT_VAC_STEP                                                                                                              \
+                {                                                                                                                 \
+                    const v3 q = p;                                                                                               \
+                    integrate_rk4_lean<SPIN, true, FMA>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, y, hy, ys, hs, hcp);              \
+                    ++k;                                                                                                          \
+                    escaped = false;                                                                                              \
+                    if (!RRT_VAC_ESC_BRANCH || __builtin_amdgcn_ballot_w64(r > 250.0f) != 0ull) { /* raymarcher.cu:120 */         \
+                        escaped = r > 250.0f && (FMA ? dot_fma(q, vel) : dot(q, vel)) > 0.0f;                                     \
+                        if (__builtin_amdgcn_ballot_w64(escaped) != 0ull) { why = 1; break; }                                     \
+                    }                                                                                                             \
+                    if (k >= a.max_steps) { why = 2; break; }                                                                     \
+                    r2 = FMA ? dot_fma(p, p) : dot(p, p);                                                                         \
+                    rejected = sqrt_seeded_yh<1>(r2, ys, hs, r, y, hy);                                                           \
+                    rej_mask = __builtin_amdgcn_ballot_w64(rejected);                                                             \
+                    if ((rej_mask | __builtin_amdgcn_ballot_w64(!(r >= kVacuumR))) != 0ull) { why = 3; break; }                   \
+                }
+                for (;;) {
+                    RRT_VAC_STEP
+#if RRT_VAC_INNER >= 2
+                    RRT_VAC_STEP
+#endif
+                }
+#undef RRT_VAC_STEP
+                if (escaped) { steps = k; break; }      /* k counts the step just taken */
+                if (why != 3) continue;
+                rel_p = p;
+            }
+            if (rej_mask != 0ull) {
+                bool small;                             /* r < 1 ends the ray at the horizon test below */
+                if (rejected) radius_fallback(r2, r, y, hy, small);
+            }
+            if (r < kEventHorizon * 1.01f) { hit = true; acc.t = 0.0f; steps = k; break; }
+            const bool near_bh = r < 18.0f;
+            const bool in_disk = fabsf(rel_p.y) < kDiskH * 5.0f && r < kDiskOut + 5.0f;
+            const bool in_cloud = fabsf(rel_p.y) < kCloudH * 1.5f && r < kCloudOut;
+            float h, hh, h6;
+            zone_step(near_bh, in_disk, h, hh, h6);
+            integrate_rk4_lean<SPIN, false, FMA>(p, vel, h, hh, h6, a.drag_c, r2, r, y, hy, ys, hs, hcp);
+            if (MEDIA != 0 && (in_disk || in_cloud)) {
+                float d_disk, d_cloud;
+                media_densities<MEDIA>(rel_p, a.time, in_disk, in_cloud, a.lut_acc, a.lut_dust, a.dust_bands, oob, d_disk, d_cloud);
+                accumulate_sample(acc, d_disk, d_cloud, rel_p, r, vel, h, a.spin);
+            }
+            ++k;
+            if (r > 250.0f && (FMA ? dot_fma(rel_p, vel) : dot(rel_p, vel)) > 0.0f) { steps = k; break; }     /* raymarcher.cu:120 */
+        }
+#else
         for (int k = i; k < a.max_steps; ++k) {
             const v3 rel_p = p;                         /* p - MASS_POS, MASS_POS = 0 */
             const float r2 = FMA ? dot_fma(rel_p, rel_p) : dot(rel_p, rel_p);
@@ -410,6 +489,7 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
             }
             if (r > 250.0f && (FMA ? dot_fma(rel_p, vel) : dot(rel_p, vel)) > 0.0f) { steps = k + 1; break; }     /* raymarcher.cu:120 */
         }
+#endif
         i = steps;
     }
 }
@@ -534,7 +614,7 @@ void raymarch_pixels(const FrameArgs a) {
     Radiance acc = {0.f, 0.f, 0.f, 1.0f};
     bool hit = false;
     int i = 0;
-    march_inline<SPIN, MEDIA, ARITH>(a, p, vel, acc, hit, i, DEBUG ? a.dbg.d_lut_oob : nullptr);
+    march_inline<SPIN, MEDIA, ARITH, true>(a, p, vel, acc, hit, i, DEBUG ? a.dbg.d_lut_oob : nullptr);
     shade_and_store<DEBUG>(a, x, y, out_row, uvx, uvy, hit, p, vel, acc, i);
     if (a.tile_cost) {          /* what this wave cost, for the next launch's order (every lane stores the same word) */
         const unsigned long long dt = (__builtin_readcyclecounter() - t_start) >> 4;

@@ -22,6 +22,9 @@ stays clear:
                      them is the sky texel filter (tex2D<float4>).  These pin
                      the per-pixel glue of the restatement (loop order, zones, RT block, sky
                      lookup, post-FX, tone map, row flip) to the reference, byte for byte.
+  frames_ref_fma.npz the same scenes (and four 320x180 views, with their strict reference frames) from the reference's kernel
+                     body compiled with floating-point contraction (g++ -ffp-contract=fast -mfma; oracle/Makefile ref-fma):
+                     what a contracting compiler does to the reference itself -- the bound for RRT_ARITH_FMAD's deviation.
   frames_oracle.npz  the same small frames rendered by the oracle RESTATEMENT in both math
                      modes, with per-ray diagnostics the reference kernel does not output
                      (final p / vel / radiance, float RGB): regression pins + GPU comparison data.
@@ -340,8 +343,53 @@ def make_frames_ref():
     print("frames_ref.npz:", len(out), "arrays")
 
 
+# Larger frames for the contraction comparison (round 6): the 64 x 36 fixtures hold too few pixels to say anything about a
+# 1e-4 class.  The strict reference frames of these cases live in frames_ref_fma.npz too (frames_ref.npz keeps its set).
+FMA_EXTRA_CASES = {
+    "B1": (320, 180, 0.9, 1, ((0.0, 10.0, -60.0), 0.0, -10.0), 1.0, {}),                  # the bench view (main.cpp:128-130)
+    "B2": (320, 180, 0.9, 0, ((0.0, 10.0, -60.0), 0.0, -10.0), 1.0, {}),                  # ... skybox only: contraction of the geodesic code alone
+    "B3": (320, 180, 0.9, 1, ((15.0, 3.0, -30.0), -20.0, -5.0), 3.0, {}),                 # path 0 key 1 (camera_paths.cpp:35)
+    "B4": (320, 180, 0.9, 1, ((4.2, 0.6, 4.2), -90.0, -5.7), 14.0, {}),                   # from inside the disk (camera_paths.cpp:62)
+}
+
+
+def make_frames_ref_fma():
+    """frames_ref_fma.npz: the reference's own kernel body compiled with floating-point CONTRACTION (oracle/Makefile ref-fma:
+    the same piped text and headers under g++ -ffp-contract=fast -mfma) on every REF_FRAME_CASES scene and on four 320 x 180
+    views, for which the strict reference frames are stored alongside.  RGBA8 + per-ray step counts.  What a contracting
+    compiler does to raymarcher.cu:15-174 itself: the yardstick RRT_ARITH_FMAD's deviation is held against
+    (tests/test_oracle_frames.py, tests/test_gpu_tolerance.py)."""
+    if not po.ref_frames_fma_available():
+        po.build(ref=True)
+    sky = synthetic_sky()
+    out = {}
+    cases = dict(REF_FRAME_CASES)
+    cases.update(FMA_EXTRA_CASES)
+    for name, (w, h, spin, vol, camspec, t, fxkw) in cases.items():
+        cam_arr, _ = frame_camera(camspec)
+        fx = po.default_effects(**fxkw)
+        out[f"{name}_camera"] = cam_arr
+        out[f"{name}_scene"] = np.array([w, h, spin, vol, t], np.float64)
+        out[f"{name}_fx_flags"] = np.array([fx.use_bloom, fx.use_vignette, fx.use_ca, fx.use_lens], np.int32)
+        out[f"{name}_fx_vals"] = np.array([fx.bloom_threshold, fx.bloom_intensity, fx.vignette_intensity,
+                                           fx.ca_amount, fx.distortion_amount], np.float32)
+        r = po.ref_render(cam_arr, fx, spin, vol, t, w, h, sky, fma=True)
+        out[f"{name}_fma_rgba8"] = r["rgba8"]
+        out[f"{name}_fma_steps"] = r["steps"].astype(np.int16)
+        if name in FMA_EXTRA_CASES:
+            rs = po.ref_render(cam_arr, fx, spin, vol, t, w, h, sky)
+            out[f"{name}_rgba8"] = rs["rgba8"]
+            out[f"{name}_steps"] = rs["steps"].astype(np.int16)
+        print(name, "contracted reference kernel: mean steps %.1f" % r["steps"].mean())
+    np.savez_compressed(os.path.join(HERE, "frames_ref_fma.npz"), **out)
+    print("frames_ref_fma.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     po.build(ref=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "frames_ref_fma":
+        make_frames_ref_fma()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "frames_ref":
         make_frames_ref()
         sys.exit(0)
@@ -357,3 +405,4 @@ if __name__ == "__main__":
     make_frames_ref()
     make_rk4_chains()
     make_sky()
+    make_frames_ref_fma()

@@ -188,7 +188,7 @@ def test_bench_self_launches_its_ranks():
     env = dict(os.environ, RRT_DIST_BACKEND="gloo")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--width", "320", "--height", "180", "--steps", "2",
-                        "--warmup", "1", "--cpu-stride", "0", "--workspace-gib", "2"], cwd=ROOT, env=env, capture_output=True,
+                        "--warmup", "1", "--cpu-stride", "4", "--workspace-gib", "2"], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -196,6 +196,12 @@ def test_bench_self_launches_its_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["comm_ranks"] == 2
     assert d["scaling"] == "strong" and d["value"] > 0
+    # round 6: the N > 1 line carries the CPU leg too (rank 0 times it while the other rank waits at a barrier under the run
+    # watchdog; no rank trips one: the run ended with status 0 above), on the threads it actually had
+    cb = d["cpu_baseline"]
+    assert cb is not None and cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("port", "reference") and "barrier" in cb["note"]
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_frames.so")):
+        assert cb["kind"] == "reference"
     # round 3: the N > 1 line explains its own efficiency -- every rank's phase latencies (render | gather | assemble)
     # and the same frames one at a time (latency-bound strong scaling) next to the pipelined value
     mg = d["multi_gpu"]
@@ -254,6 +260,14 @@ def test_bench_line_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["frac"] < 1
+    # round 6: what the K timed frames did, not only their mean
+    assert len(rf["kernel_ms_per_frame"]) == 2 and rf["kernel_ms_min"] <= rf["kernel_ms_median"] <= rf["kernel_ms_max"]
+    assert rf["kernel_ms_min"] <= rf["kernel_ms"] <= rf["kernel_ms_max"] and rf["kernel_ms_slowest_frame"] in (0, 1)
+    assert rf["kernel_ms_per_frame"][rf["kernel_ms_slowest_frame"]] == rf["kernel_ms_max"]
+    # ... and the 30 fps statement may only rest on a mode whose arithmetic is not narrower than the reference's build
+    wt = d["within_tolerance_mode"]
+    assert wt["mode"] in ("fmad", None) and wt["modes"]["fast"]["credited"] is False and wt["modes"]["fmad"]["credited"] is True
+    assert wt["conditioning"]["uncovered_after_fixed_set"]["frames"] == 20 and 0 <= wt["conditioning"]["ill_fraction"] < 0.25
     # round 4: the clock the chip held over the timed frames, and the fraction priced at it
     assert 1.0 < rf["clock_ghz"] < 2.6 and "beside the timed frames" in rf["clock_note"]
     assert abs(rf["frac_at_held_clock"] - rf["achieved"] / (256 * 4 * 32 * rf["clock_ghz"] / 1e3)) < 2e-3
