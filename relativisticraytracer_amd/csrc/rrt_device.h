@@ -80,6 +80,9 @@ __host__ __device__ static inline float rrt_div_const(float a, const float B) { 
 
 #include "rrt_math.h"
 
+#ifndef RRT_PROBE
+#define RRT_PROBE 0
+#endif
 #define RRT_DEV __device__ __forceinline__
 
 namespace rrt {
@@ -206,8 +209,12 @@ RRT_DEV LutTap lut_fetch(const NoiseLut& L, v3 p, unsigned* oob) {
     t.uz = fz * fz * (3.0f - 2.0f * fz);
     const int cx = (int)ix, cy = (int)iy, cz = (int)iz;
     const unsigned want = (unsigned)(__mul24(cz, L.nxy) + __mul24(cy, L.nx) + cx - L.origin);
-    const unsigned idx = want < L.last ? want : L.last;
+    unsigned idx = want < L.last ? want : L.last;
     if (oob && want > L.last) atomicAdd(oob, 1u);
+#if defined(RRT_PROBE) && (RRT_PROBE & 16)     /* timing probe (wrong pixels): every lane reads the FIRST lane's cell -- one line per load, what a
+                                                 * perfectly coalesced / LDS-broadcast lookup could cost at best */
+    idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+#endif
     const char* base = reinterpret_cast<const char*>(L.cells);
     t.q0 = *reinterpret_cast<const float4*>(base + (size_t)(idx << 4));
     t.q1 = *reinterpret_cast<const float4*>(base + (size_t)((idx + (unsigned)L.nxy) << 4));
@@ -808,11 +815,8 @@ RRT_DEV float disk_temperature_t(float r) {
 RRT_DEV float disk_temperature(float r) { return disk_temperature_t<false>(r); }
 
 /* RRT_PROBE (dev builds only, wrong pixels): bit 0 drops the accretion density, bit 1 the dust density, bit 2 the
- * emission block, bit 3 replaces every noise3D by a cheap expression -- timing probes that apportion the media cost
- * (tools/ab_views.py; profiles/README.md round 3). */
-#ifndef RRT_PROBE
-#define RRT_PROBE 0
-#endif
+ * emission block, bit 3 replaces every noise3D by a cheap expression, bit 4 makes every table lookup of a wave read one
+ * cell (lut_fetch) -- timing probes that apportion the media cost (tools/ab_views.py; profiles/README.md round 3). */
 /* unroll factors of the media loops (1 = rolled, the shipped form; A/B builds override them) */
 #define RRT_PRAGMA_STR(x) _Pragma(#x)
 #define RRT_PRAGMA_UNROLL(n) RRT_PRAGMA_STR(unroll n)

@@ -314,15 +314,6 @@ __device__ __forceinline__ void zone_step(bool near_bh, bool in_disk, float& h, 
 #ifndef RRT_VACUUM_PATH
 #define RRT_VACUUM_PATH 1
 #endif
-/* RRT_VAC_INNER = N > 0: the single kernel's vacuum steps run in a loop of their own, unrolled N times (march_inline);
- * 0: round 3-5's flat loop. */
-#ifndef RRT_VAC_INNER
-#define RRT_VAC_INNER 2
-#endif
-/* the escape test's dot product behind a wave-uniform `some lane is beyond r = 250` (1), or evaluated on every step (0) */
-#ifndef RRT_VAC_ESC_BRANCH
-#define RRT_VAC_ESC_BRANCH 1
-#endif
 #ifndef RRT_HORIZON_IN_GENERIC
 #define RRT_HORIZON_IN_GENERIC 0
 #endif
@@ -367,6 +358,54 @@ __device__ __forceinline__ void march_inline_v1(const FrameArgs& a, v3& p, v3& v
     i = steps;
 }
 
+/* Round 6: the vacuum steps of a wavefront in a loop of their own, every exit of which is wave-uniform.  In the flat loop
+ * of rounds 3-5 the vacuum and the generic path met before the back edge, and the step that is taken nine times in ten paid
+ * the register copies of that meeting (FMAD: 14 v_mov on 221 arithmetic instructions; strict: 5 on 278).  Here the
+ * loop-carried state has one producer; with the body written out twice a step can write its results into the registers of
+ * the state before last, which the escape test (pre-step position, post-step velocity: raymarcher.cu:120) has released by
+ * then: 220 VALU per FMAD vacuum step, 281 strict, no copy left (tools/isa_histogram.py; 4K bench frame 32.2 -> 30.3 ms
+ * FMAD, 37.2 -> 35.9 strict, same bytes: profiles/r06_vac_inner_ab.txt).  A lane that escapes does not leave by itself -- a
+ * divergent exit would make the step counter a per-lane value: the WAVE leaves (1), the escaped lanes end their march at the
+ * caller, the others come back in.
+ * In: the loop-top radius (r2, r, y, hy) of p, accepted and >= kVacuumR in every live lane.  Returns why the wave left:
+ * 1 = a lane escaped (`escaped`; k counts its last step), 2 = out of steps, 3 = some lane needs the generic step: (r2, r, y,
+ * hy, rejected, rej_mask) are then the loop-top values of the new p. */
+#ifndef RRT_VAC_INNER
+#define RRT_VAC_INNER 2
+#endif
+/* the escape test's dot product behind a wave-uniform `some lane is beyond r = 250` (1), or evaluated on every step (0:
+ * 0.4 ms slower on the 4K frame) */
+#ifndef RRT_VAC_ESC_BRANCH
+#define RRT_VAC_ESC_BRANCH 1
+#endif
+template <bool SPIN, bool FMA>
+__device__ __forceinline__ int vacuum_run(v3& p, v3& vel, float drag_c, int& k, int max_steps, float& r2, float& r, float& y, float& hy,
+                                          float& ys, float& hs, float& hcp, bool& rejected, unsigned long long& rej_mask, bool& escaped) {
+#define RRT_VAC_STEP                                                                                                  \
+    {                                                                                                                 \
+        const v3 q = p;                                                                                               \
+        integrate_rk4_lean<SPIN, true, FMA>(p, vel, 0.f, 0.f, 0.f, drag_c, r2, r, y, hy, ys, hs, hcp);                \
+        ++k;                                                                                                          \
+        escaped = false;                                                                                              \
+        if (!RRT_VAC_ESC_BRANCH || __builtin_amdgcn_ballot_w64(r > 250.0f) != 0ull) { /* raymarcher.cu:120 */         \
+            escaped = r > 250.0f && (FMA ? dot_fma(q, vel) : dot(q, vel)) > 0.0f;                                     \
+            if (__builtin_amdgcn_ballot_w64(escaped) != 0ull) return 1;                                               \
+        }                                                                                                             \
+        if (k >= max_steps) return 2;                                                                                 \
+        r2 = FMA ? dot_fma(p, p) : dot(p, p);                                                                         \
+        rejected = sqrt_seeded_yh<1>(r2, ys, hs, r, y, hy);                                                           \
+        rej_mask = __builtin_amdgcn_ballot_w64(rejected);                                                             \
+        if ((rej_mask | __builtin_amdgcn_ballot_w64(!(r >= kVacuumR))) != 0ull) return 3;                             \
+    }
+    for (;;) {
+        RRT_VAC_STEP
+#if RRT_VAC_INNER >= 2
+        RRT_VAC_STEP
+#endif
+    }
+#undef RRT_VAC_STEP
+}
+
 /* UK: every lane of the wave enters at the same step `i` (the single kernel: 0), so the step counter is one number per wave;
  * the loop says so once per outer iteration (v_readfirstlane), which keeps the counter and the vacuum loop's exit code in
  * scalar registers whatever the compiler makes of the merged exits of the outer loop. */
@@ -381,13 +420,7 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
         float ys = 0.0f, hs = 0.0f;                     /* (1/r, 1/(2r)) estimate for the next loop-top radius; 0: none yet */
         float hcp = 0.0f;                               /* 1/(2r) at the previous vacuum step's stage 3 (seed extrapolation) */
 #if RRT_VAC_INNER
-        /* Round 6: the vacuum steps of a wavefront in a loop of their own, every exit of which is wave-uniform.  In the flat
-         * loop (#else) the vacuum and the generic path meet before the back edge, and the step that is taken nine times in
-         * ten paid the register copies of that meeting (FMAD: 14 v_mov on 221 arithmetic instructions).  Here the
-         * loop-carried state has one producer; with the body written out twice a step can write its results into the
-         * registers of the state before last, which the escape test (pre-step position, post-step velocity:
-         * raymarcher.cu:120) has released by then.  A lane that escapes does not leave by itself (a divergent exit would make
-         * the step counter a per-lane value): the wave leaves, the escaped lanes end their march, the others re-enter. */
+        /* vacuum steps in a loop of their own (vacuum_run); #else: the flat loop of rounds 3-5 */
         int k = i;
         while (k < a.max_steps) {
             if (UK) k = __builtin_amdgcn_readfirstlane(k);
@@ -399,30 +432,7 @@ __device__ __forceinline__ void march_inline(const FrameArgs& a, v3& p, v3& vel,
             unsigned long long rej_mask = __builtin_amdgcn_ballot_w64(rejected);
             if (RRT_VACUUM_PATH && (rej_mask | __builtin_amdgcn_ballot_w64(!(r >= kVacuumR))) == 0ull) {
                 bool escaped;
-                int why;                                /* 1: a lane escaped; 2: out of steps; 3: a lane needs the generic step */
-#define RRT_VAC_STEP                                                                                                              \
-                {                                                                                                                 \
-                    const v3 q = p;                                                                                               \
-                    integrate_rk4_lean<SPIN, true, FMA>(p, vel, 0.f, 0.f, 0.f, a.drag_c, r2, r, y, hy, ys, hs, hcp);              \
-                    ++k;                                                                                                          \
-                    escaped = false;                                                                                              \
-                    if (!RRT_VAC_ESC_BRANCH || __builtin_amdgcn_ballot_w64(r > 250.0f) != 0ull) { /* raymarcher.cu:120 */         \
-                        escaped = r > 250.0f && (FMA ? dot_fma(q, vel) : dot(q, vel)) > 0.0f;                                     \
-                        if (__builtin_amdgcn_ballot_w64(escaped) != 0ull) { why = 1; break; }                                     \
-                    }                                                                                                             \
-                    if (k >= a.max_steps) { why = 2; break; }                                                                     \
-                    r2 = FMA ? dot_fma(p, p) : dot(p, p);                                                                         \
-                    rejected = sqrt_seeded_yh<1>(r2, ys, hs, r, y, hy);                                                           \
-                    rej_mask = __builtin_amdgcn_ballot_w64(rejected);                                                             \
-                    if ((rej_mask | __builtin_amdgcn_ballot_w64(!(r >= kVacuumR))) != 0ull) { why = 3; break; }                   \
-                }
-                for (;;) {
-                    RRT_VAC_STEP
-#if RRT_VAC_INNER >= 2
-                    RRT_VAC_STEP
-#endif
-                }
-#undef RRT_VAC_STEP
+                const int why = vacuum_run<SPIN, FMA>(p, vel, a.drag_c, k, a.max_steps, r2, r, y, hy, ys, hs, hcp, rejected, rej_mask, escaped);
                 if (escaped) { steps = k; break; }      /* k counts the step just taken */
                 if (why != 3) continue;
                 rel_p = p;
@@ -677,15 +687,31 @@ __global__ __launch_bounds__(kWGThreads, RRT_DEFER_WAVES) RRT_DEFER_SGPR_ATTR vo
     constexpr bool LEAN = !FAST && RRT_MARCH_V2;               /* round 3's step (march_inline has the notes) */
     float y_seed = 0.0f, h_seed = 0.0f, hc_prev = 0.0f;        /* a resumed ray starts without seeds: its first root takes the
                                                                 * v_rsq fall-back, which is the same correctly rounded root */
+    /* `i` is a per-lane variable only across rounds: the lanes that march in a round all start at the same step (0, or the
+     * step the pool ran out at, which is a wave-uniform event) -- but a first round can PROVE it to the compiler-independent
+     * v_readfirstlane below, a resumed one only by that argument, so only the first round keeps the counter scalar */
+    constexpr bool UK = !RESUME && LEAN && RRT_VAC_INNER;
     for (; active && i < a.max_steps; ++i) {
-        const v3 rel_p = p;
+        if (UK) i = __builtin_amdgcn_readfirstlane(i);
+        v3 rel_p = p;
         float r2, r, yv, hv = 0.0f;
         bool vacuum = false;
         if constexpr (LEAN) {
             r2 = FMA ? dot_fma(rel_p, rel_p) : dot(rel_p, rel_p);
-            const bool rejected = sqrt_seeded_yh<1>(r2, y_seed, h_seed, r, yv, hv);
-            const unsigned long long rej_mask = __builtin_amdgcn_ballot_w64(rejected);
+            bool rejected = sqrt_seeded_yh<1>(r2, y_seed, h_seed, r, yv, hv);
+            unsigned long long rej_mask = __builtin_amdgcn_ballot_w64(rejected);
             vacuum = RRT_VACUUM_PATH && (rej_mask | __builtin_amdgcn_ballot_w64(!(r >= kVacuumR))) == 0ull;
+#if RRT_VAC_INNER
+            if (vacuum) {                                          /* the vacuum steps in their own loop (vacuum_run) */
+                bool escaped;
+                const int why = vacuum_run<SPIN, FMA>(p, vel, a.drag_c, i, a.max_steps, r2, r, yv, hv, y_seed, h_seed, hc_prev, rejected,
+                                                      rej_mask, escaped);
+                if (escaped) break;                                /* i counts the step just taken */
+                if (why != 3) { --i; continue; }                   /* (the loop's own ++i) */
+                rel_p = p;
+                vacuum = false;
+            }
+#endif
             if (!vacuum && rej_mask != 0ull) {
                 bool small;
                 if (rejected) radius_fallback(r2, r, yv, hv, small);

@@ -49,6 +49,24 @@ def frames_ref():
 
 
 @pytest.fixture(scope="session")
+def frames_ref_fma():
+    """The reference's kernel body compiled with floating-point CONTRACTION (make_golden.py::make_frames_ref_fma), on the
+    frames_ref.npz scenes and four 320x180 views (B1-B4, whose strict reference frames are in the same file)."""
+    return dict(np.load(os.path.join(GOLDEN, "frames_ref_fma.npz")))
+
+
+def contraction_counts(strict8, strict_steps, other8, other_steps):
+    """How far a frame is from the strict reference frame, in the only units the reference's kernel outputs: pixels with a
+    differing byte, pixels with a byte off by more than one LSB, pixels with another RK4 step count.  rgba8 (h, w, 4) bottom-up,
+    steps (h*w,) top-down (the fixtures' layouts).  Returns (counts dict, deviant mask (h, w) bottom-up)."""
+    h, w = strict8.shape[:2]
+    d = np.abs(strict8.astype(int) - other8.astype(int))[..., :3].max(axis=2)
+    sd = (np.asarray(strict_steps).astype(int) != np.asarray(other_steps).astype(int)).reshape(h, w)[::-1]
+    return ({"pixels": h * w, "bytes_differ": int((d > 0).sum()), "off_by_more_than_1": int((d > 1).sum()), "steps_differ": int(sd.sum()),
+             "deviant": int(((d > 1) | sd).sum()), "max_byte_diff": int(d.max())}, (d > 1) | sd)
+
+
+@pytest.fixture(scope="session")
 def camera_ref():
     return dict(np.load(os.path.join(GOLDEN, "camera_ref.npz")))
 

@@ -156,3 +156,56 @@ def test_mode_renders_the_same_bytes_on_every_path(ctx, mode):
             assert torch.equal(out, want), (view, "tiles")
         finally:
             ws.destroy()
+
+
+def test_fmad_deviates_less_than_a_contracted_reference(ctx, frames_ref, frames_ref_fma):
+    """Round 6: RRT_ARITH_FMAD is offered as "the arithmetic class of the reference's own build" (nvcc defaults:
+    multiply-adds contracted, IEEE divide and square root).  What contraction does to the REFERENCE ITSELF is on record:
+    tests/golden/frames_ref_fma.npz = the reference's kernel text compiled by a second, independent contracting compiler
+    (g++ -ffp-contract=fast -mfma; oracle/Makefile ref-fma), twelve scenes.  Per scene, against the strictly compiled reference
+    frame: pixels with another RK4 step count, pixels with a byte off by more than one LSB, pixels with any byte differing --
+    for the contracted reference and for the HIP FMAD frame.  FMAD must deviate no more than the contracted reference does, in
+    total and (up to three pixels of counting noise on scenes where both counts are a handful) per scene; the strict HIP
+    frame's own distance to the reference (<= 1 LSB on <= 1e-4 of the bytes: glibc against the portable transcendentals) is
+    printed beside it.  The contracted reference is expected to be the FURTHER one: it contracts the noise hash too
+    (math_utils.h:95), which FMAD deliberately does not; on the skybox-only scenes (G2, B2) only the geodesic code can differ
+    and the two are the same class.  Also printed: how many of each side's deviant pixels lie on the conditioning map."""
+    import gpu_util as g
+    from conftest import contraction_counts
+    from relativisticraytracer_amd import conditioning
+    rrt, tex, nt = ctx
+    names = ("G1", "G2", "G3", "G4", "G5", "K1", "K2", "R1", "B1", "B2", "B3", "B4")
+    tot = {k: {"bytes_differ": 0, "off_by_more_than_1": 0, "steps_differ": 0, "deviant": 0} for k in ("contracted", "fmad", "strict")}
+    for name in names:
+        src = frames_ref_fma if name.startswith("B") else frames_ref
+        w, h, spin, vol, t = frames_ref_fma[f"{name}_scene"]
+        w, h, spin, vol, t = int(w), int(h), float(np.float32(spin)), int(vol), float(np.float32(t))
+        fl, fv = frames_ref_fma[f"{name}_fx_flags"], frames_ref_fma[f"{name}_fx_vals"]
+        fx = rrt.CameraEffects(useBloom=bool(fl[0]), useVignette=bool(fl[1]), useChromaticAberration=bool(fl[2]),
+                               useLensDistortion=bool(fl[3]), bloomThreshold=float(fv[0]), bloomIntensity=float(fv[1]),
+                               vignetteIntensity=float(fv[2]), caAmount=float(fv[3]), distortionAmount=float(fv[4]))
+        a = frames_ref_fma[f"{name}_camera"]
+        cam = rrt.CameraState(a[0], a[1], a[2], a[3])
+        s8, ss = src[f"{name}_rgba8"], src[f"{name}_steps"]
+        con, con_mask = contraction_counts(s8, ss, frames_ref_fma[f"{name}_fma_rgba8"], frames_ref_fma[f"{name}_fma_steps"])
+        rows = {"contracted": con}
+        masks = {"contracted": con_mask}
+        for tag, mode in (("fmad", FMAD), ("strict", 0)):
+            r = g.render_gpu(w, h, spin, vol, cam, t, tex, fx=fx, arith_mode=mode, noise_table=nt.id)
+            rows[tag], masks[tag] = contraction_counts(s8, ss, r["rgba8"], r["steps"])
+        _, ill, st = conditioning.account(tex, w, h, cam, t, (FMAD,), fx=fx, budget=60, spin=spin, volumetrics=vol, noise_table=nt.id)
+        ill = ill.cpu().numpy()
+        on_ill = {k: int((m & ill).sum()) for k, m in masks.items()}
+        print(f"{name} {w}x{h} a={spin:g} vol={vol}: " + " | ".join(
+            f"{k}: steps {v['steps_differ']}, >1 LSB {v['off_by_more_than_1']}, any byte {v['bytes_differ']}, deviant {v['deviant']} ({on_ill[k]} on the ill map)"
+            for k, v in rows.items()) + f" | ill map {int(ill.sum())} px after {st['nudged_frames']} nudged frames")
+        for k in tot:
+            for q in tot[k]:
+                tot[k][q] += rows[k][q]
+        assert rows["strict"]["steps_differ"] == 0 and rows["strict"]["off_by_more_than_1"] == 0        # the strict path: the reference's steps, <= 1 LSB
+        for q in ("steps_differ", "off_by_more_than_1", "deviant"):
+            assert rows["fmad"][q] <= rows["contracted"][q] + 3, (name, q, rows)
+        assert rows["fmad"]["bytes_differ"] <= rows["contracted"]["bytes_differ"] + 3 + rows["strict"]["bytes_differ"], (name, rows)
+    print("total:", tot)
+    for q in ("steps_differ", "off_by_more_than_1", "deviant", "bytes_differ"):
+        assert tot["fmad"][q] <= tot["contracted"][q], (q, tot)

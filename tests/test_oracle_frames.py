@@ -79,6 +79,52 @@ def test_reference_kernel_build_regenerates_the_fixture(po, frames_ref, sky):
     assert np.array_equal(r["steps"], frames_ref[f"{name}_steps"].astype(np.int32))
 
 
+FMA_CASES = ("G1", "G2", "G3", "G4", "G5", "K1", "K2", "R1", "B1", "B2", "B3", "B4")
+
+
+def strict_reference_frame(frames_ref, frames_ref_fma, name):
+    src = frames_ref_fma if name.startswith("B") else frames_ref
+    return src[f"{name}_rgba8"], src[f"{name}_steps"]
+
+
+def test_what_contraction_does_to_the_reference_itself(frames_ref, frames_ref_fma):
+    """frames_ref_fma.npz: the reference's kernel text under g++ -ffp-contract=fast -mfma (oracle/Makefile ref-fma) against the
+    same text compiled strictly.  A contracting compiler -- nvcc's default for the reference's own build is one -- moves the
+    reference's frames by this class: step counts change on a few rays per 10^4, a few bytes per 10^3 move (hash31's
+    fmodf((p3.x + p3.y) * p3.z, 1), math_utils.h:95, turns one fused product into an O(1) change of a lattice value), and on
+    the skybox-only frame, where only the geodesic code can contract, step counts still change.  These counts are the yardstick
+    RRT_ARITH_FMAD is held against on the GPU (tests/test_gpu_tolerance.py::test_fmad_deviates_less_than_a_contracted_reference)."""
+    from conftest import contraction_counts
+    total = {"bytes_differ": 0, "off_by_more_than_1": 0, "steps_differ": 0, "pixels": 0}
+    for name in FMA_CASES:
+        s8, ss = strict_reference_frame(frames_ref, frames_ref_fma, name)
+        c, _ = contraction_counts(s8, ss, frames_ref_fma[f"{name}_fma_rgba8"], frames_ref_fma[f"{name}_fma_steps"])
+        print(name, c)
+        for k in total:
+            total[k] += c[k]
+        assert c["bytes_differ"] <= 0.02 * c["pixels"] and c["steps_differ"] <= 0.002 * c["pixels"] + 2, (name, c)   # the same picture ...
+    print("total", total)
+    assert total["steps_differ"] >= 10 and total["off_by_more_than_1"] >= 10 and total["bytes_differ"] >= 500           # ... but not the same bytes
+    b2, _ = contraction_counts(*strict_reference_frame(frames_ref, frames_ref_fma, "B2"), frames_ref_fma["B2_fma_rgba8"], frames_ref_fma["B2_fma_steps"])
+    assert b2["steps_differ"] >= 1          # no media on B2: contraction of geodesics.h / integrators.h alone changes step counts
+
+
+@pytest.mark.skipif(not __import__("os").path.exists("/root/reference/src/raymarcher.cu"),
+                    reason="the reference is only present in the build container")
+def test_contracted_reference_build_regenerates_the_fixture(po, frames_ref_fma, sky):
+    """Build container only: oracle/_ref/libref_frames_fma.so re-renders two cases of the committed fixture (and the strict
+    library the strict frame stored beside one of them)."""
+    po.build(ref=True)
+    for name in ("G5", "B2"):
+        w, h, spin, vol, t = frames_ref_fma[f"{name}_scene"]
+        _, fx, _, tt, w, h = ref_case(po, frames_ref_fma, name)
+        r = po.ref_render(frames_ref_fma[f"{name}_camera"], fx, float(np.float32(spin)), int(vol), tt, w, h, sky, fma=True)
+        assert np.array_equal(r["rgba8"], frames_ref_fma[f"{name}_fma_rgba8"]), name
+        assert np.array_equal(r["steps"], frames_ref_fma[f"{name}_fma_steps"].astype(np.int32)), name
+    r = po.ref_render(frames_ref_fma["B2_camera"], fx, float(np.float32(spin)), int(vol), tt, w, h, sky)
+    assert np.array_equal(r["rgba8"], frames_ref_fma["B2_rgba8"]) and np.array_equal(r["steps"], frames_ref_fma["B2_steps"].astype(np.int32))
+
+
 @pytest.mark.skipif(not __import__("os").path.exists("/root/reference/src/raymarcher.cu"),
                     reason="the reference is only present in the build container")
 def test_restatement_equals_the_reference_kernel_on_random_scenes(po, sky):
