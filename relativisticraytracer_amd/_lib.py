@@ -56,6 +56,11 @@ class rrt_debug_outputs(C.Structure):
                 ("d_rad", C.c_void_p), ("d_lut_oob", C.c_void_p)]
 
 
+class rrt_path_chooser_stats(C.Structure):
+    _fields_ = [("incumbent", C.c_int32), ("windows", C.c_int32), ("trials", C.c_int32), ("trials_aborted", C.c_int32),
+                ("switches", C.c_int32), ("outliers", C.c_int32), ("frames", C.c_int32 * 2), ("last_three_pass_median_ms", C.c_float)]
+
+
 # every symbol include/rrt.h declares: (name, restype, argtypes)
 _vp, _i, _f, _ull = C.c_void_p, C.c_int, C.c_float, C.c_ulonglong
 _cam, _fx, _prm = C.POINTER(rrt_camera), C.POINTER(rrt_effects), C.POINTER(rrt_params)
@@ -116,6 +121,11 @@ SYMBOLS = [
     ("rrt_path_keyframes", _i, [_i, _vp, _i]),
     ("rrt_path_camera_at", _i, [_i, _f, _cam]),
     ("rrt_recording_clock", _i, [_i, _i, C.POINTER(_f), C.POINTER(_f)]),
+    ("rrt_path_chooser_create", _i, [_i, _i, C.POINTER(_i)]),
+    ("rrt_path_chooser_destroy", _i, [_i]),
+    ("rrt_path_chooser_policy", _i, [_i, _i, C.POINTER(_i)]),
+    ("rrt_path_chooser_report", _i, [_i, _i, _f]),
+    ("rrt_path_chooser_get_stats", _i, [_i, _vp]),
 ]
 
 # include/rrt_test.h: librrt_hip_test.so only

@@ -19,8 +19,9 @@ TEST_LIB = os.path.join(LIBDIR, "librrt_hip_test.so")   # the same sources + -DR
 SOURCES = [os.path.join(CSRC, "rrt_hip.hip")]
 COMPAT_SRC = os.path.join(CSRC, "rrt_compat.cpp")     # launch_raymarch under the reference's mangled name (host only, g++)
 CAMERA_SRC = os.path.join(CSRC, "rrt_camera.cpp")     # camera basis / path playback (host only, g++)
+CHOOSER_SRC = os.path.join(CSRC, "rrt_path_chooser.cpp")   # per-window path choice of the animation drivers (host only, g++)
 HEADERS = [os.path.join(CSRC, f) for f in ("rrt_device.h", "rrt_math.h", "rrt_tile_sort.h", "rrt_kernels.h", "rrt_test_hooks.h")] + [
-    COMPAT_SRC, CAMERA_SRC, os.path.join(PKG, "..", "include", "rrt.h"), os.path.join(PKG, "..", "include", "rrt_test.h"),
+    COMPAT_SRC, CAMERA_SRC, CHOOSER_SRC, os.path.join(PKG, "..", "include", "rrt.h"), os.path.join(PKG, "..", "include", "rrt_test.h"),
     os.path.join(PKG, "..", "include", "raymarcher.h")]
 
 # -ffp-contract=off: the kernels' arithmetic contract (csrc/rrt_device.h).
@@ -53,9 +54,9 @@ def is_stale():
 
 
 def host_objects(outdir):
-    """the two plain-C++ translation units (g++): the reference-mangled launch_raymarch and the camera code"""
+    """the plain-C++ translation units (g++): the reference-mangled launch_raymarch, the camera code, the path chooser"""
     objs = []
-    for src in (COMPAT_SRC, CAMERA_SRC):
+    for src in (COMPAT_SRC, CAMERA_SRC, CHOOSER_SRC):
         obj = os.path.join(outdir, os.path.splitext(os.path.basename(src))[0] + ".o")
         subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-Wall", "-c", src, "-o", obj], check=True)
         objs.append(obj)

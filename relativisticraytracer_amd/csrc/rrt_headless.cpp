@@ -6,6 +6,7 @@
 //
 //   rrt_headless --width 1000 --height 700 --frames 24 --path 0 --spin 0.9 --out frames.rgba [--sky-seed 1]
 //                [--gpus N] [--tile-rows 16] [--workspace-gib G] [--noise-table-gib B | --no-noise-table]
+//                [--arith strict|fmad|fast] [--path-window F | --path-window -1]
 //                [--init-timeout 300] [--frame-timeout 120]      (watchdog, seconds; exit status 3 when it fires)
 //
 // Noise tables: the reference's simTime runs without bound (main.cpp:515) and a table's size grows with the times
@@ -190,12 +191,19 @@ struct Device {                // everything one GPU owns
     ncclComm_t comm = nullptr;
     void* probe = nullptr;                        // 256 B to send + 256 B per peer to receive: the bring-up exchange
     hipEvent_t comm_free = nullptr;               // after this device's part of the last exchange (orders the next one behind it)
+    // per-window path choice (include/rrt.h: rrt_path_chooser_*): the end of every frame's render on this device, kept for
+    // 2 * kMaxSlots frames so that frame k - 1's event is still frame k - 1's when frame k is delivered
+    int chooser = 0;
+    hipEvent_t render_end[2 * kMaxSlots] = {};
 };
 
 }  // namespace
 
 int main(int argc, char** argv) {
-    int w = 1000, h = 700, frames = 24, fps = 24, path = -1, sky_seed = 1, all_fx = 0, fast = 0;   // config.h:7-9
+    int w = 1000, h = 700, frames = 24, fps = 24, path = -1, sky_seed = 1, all_fx = 0;   // config.h:7-9
+    int arith = RRT_ARITH_STRICT;  // --arith strict | fmad | fast (--fast = --arith fast)
+    int path_window = 0;           // frames per window of the per-rank path choice (0: the library's default, 48); -1: no choice, the
+                                   // three-pass path for every small share as in rounds 1-5
     int gpus = 1, tile_rows = 16, workspace_gib = 2, use_table = 1, force_collective = 0;
     int tile_order = -1;           // cost-ordered dispatch: -1 auto (on when frames are rendered one at a time), 0 off, 1 on
     int kSlots = 3;                // frames in flight: frame k renders on stream k mod kSlots while its predecessors are
@@ -220,7 +228,13 @@ int main(int argc, char** argv) {
         else if (a == "--tile-order") tile_order = 1; else if (a == "--no-tile-order") tile_order = 0;
         else if (a == "--force-collective") force_collective = 1;     // run the RCCL exchange even with one GPU (self-check)
         else if (a == "--out" && i + 1 < argc) out_path = argv[++i];
-        else if (a == "--all-effects") all_fx = 1; else if (a == "--fast") fast = 1;
+        else if (a == "--all-effects") all_fx = 1; else if (a == "--fast") arith = RRT_ARITH_FAST;
+        else if (a == "--path-window") val(path_window);
+        else if (a == "--arith" && i + 1 < argc) {
+            const std::string m = argv[++i];
+            if (m == "strict") arith = RRT_ARITH_STRICT; else if (m == "fmad") arith = RRT_ARITH_FMAD; else if (m == "fast") arith = RRT_ARITH_FAST;
+            else { fprintf(stderr, "--arith strict | fmad | fast\n"); return 2; }
+        }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     if (w <= 0 || h <= 0 || frames < 0 || fps <= 0 || gpus < 1 || tile_rows < 1 || kSlots < 1 || kSlots > kMaxSlots) {
@@ -276,6 +290,12 @@ int main(int argc, char** argv) {
         if ((rc = rrt_sky_create(sky.data(), 2048, 1024, &D.sky)) != RRT_OK) return fail("sky", rc);
         HIPCHK(hipMalloc(&D.probe, 256 * (size_t)(gpus + 1)));
         HIPCHK(hipEventCreateWithFlags(&D.comm_free, hipEventDisableTiming));
+        // the path is a choice only where a launch could take either: a pool, a share under RRT_PATH_AUTO's threshold, frames in
+        // flight (one frame at a time the three-pass path's two chains win: DESIGN.md section 5)
+        if (path_window >= 0 && kSlots >= 2 && workspace_gib > 0 && (long long)w * rows <= (long long)rrt_path_auto_max_rays()) {
+            if ((rc = rrt_path_chooser_create(kSlots, path_window, &D.chooser)) != RRT_OK) return fail("path chooser", rc);
+            for (int e = 0; e < 2 * kSlots; ++e) HIPCHK(hipEventCreate(&D.render_end[e]));
+        }
         for (int s = 0; s < kSlots; ++s) {
             HIPCHK(hipStreamCreateWithFlags(&D.stream[s], hipStreamNonBlocking));
             HIPCHK(hipMalloc(&D.tiles[s], shard_stride));
@@ -343,6 +363,14 @@ int main(int argc, char** argv) {
     auto deliver = [&](int slot) -> int {
         HIPCHK(hipEventSynchronize(done[slot]));
         trace("frame complete", ++delivered);
+        // frame `delivered` has been rendered on every device (the gather waited for all shards): its sustained time on a device =
+        // the interval between the ends of frame delivered - 1's and its own render there
+        if (delivered >= 2) for (int d = 0; d < gpus; ++d) if (dev[d].chooser) {
+            float ms = 0.0f;
+            HIPCHK(hipSetDevice(d));
+            if (hipEventElapsedTime(&ms, dev[d].render_end[(delivered - 1) % (2 * kSlots)], dev[d].render_end[delivered % (2 * kSlots)]) == hipSuccess)
+                rrt_path_chooser_report(dev[d].chooser, delivered, ms > 0.0f ? ms : 0.0f);   // (a frame that ended before its predecessor: 0)
+        }
         if (f && fwrite(host[slot], 1, frame_bytes, f) != frame_bytes) fprintf(stderr, "Warning: Frame write incomplete\n");
         return 0;
     };
@@ -403,17 +431,22 @@ int main(int argc, char** argv) {
             Device& D = dev[d];
             HIPCHK(hipSetDevice(d));
             rrt_params prm; rrt_params_default(&prm);
-            prm.spin = spin; prm.arith_mode = fast ? RRT_ARITH_FAST : RRT_ARITH_STRICT;
+            prm.spin = spin; prm.arith_mode = arith;
             prm.workspace = D.pool[slot]; prm.noise_table = D.noise_table; prm.tile_order = D.order[slot];
             // frames in flight fill each other's drains: ONE chain per launch (the second chain's streams only compete with the other
             // frames: 2-7 % per frame, profiles/r05_sustained_chains.txt).  The plain single kernel would be faster still on most views,
             // but its longest wavefront (up to 19 ms on a disk-grazing view) bounds a slot's frame rate; a moving camera keeps the
             // path that is never slow
             prm.pass_chains = kSlots >= 2 ? 1 : 0;
+            // ... per window, by measurement: rrt_path_chooser (csrc/rrt_path_chooser.cpp) tries the single kernel for a few frames
+            // of a window, keeps it where it sustains the faster frames, and drops it at once on a frame that takes > 1.5 x the
+            // three-pass median (same bytes either way)
+            if (D.chooser) { int pol = RRT_PATH_AUTO; rrt_path_chooser_policy(D.chooser, k, &pol); prm.path_policy = pol; }
             void* dst = collective ? D.tiles[slot] : frame[slot];
             if (collective) rc = rrt_launch_raymarch_tiles(dst, w, h, tile_rows, d, gpus, sim_t, &cam, D.sky, &fx, &prm, D.stream[slot]);
             else rc = rrt_launch_raymarch(dst, w, h, sim_t, &cam, D.sky, &fx, &prm, D.stream[slot]);
             if (rc != RRT_OK) return fail("launch", rc);
+            if (D.chooser) HIPCHK(hipEventRecord(D.render_end[k % (2 * kSlots)], D.stream[slot]));
         }
         // 2. one gather: every device sends its shard, device 0 receives all of them (its own included)
         if (collective) {
@@ -448,12 +481,28 @@ int main(int argc, char** argv) {
     for (int d = 0; d < gpus; ++d) { HIPCHK(hipSetDevice(d)); HIPCHK(hipDeviceSynchronize()); }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (f) fclose(f);
+    std::string choice = "null";
+    if (dev[0].chooser) {
+        choice = "[";
+        for (int d = 0; d < gpus; ++d) {
+            rrt_path_chooser_stats st;
+            rrt_path_chooser_get_stats(dev[d].chooser, &st);
+            char buf[256];
+            snprintf(buf, sizeof(buf), "%s{\"device\": %d, \"frames_three_pass\": %d, \"frames_single_kernel\": %d, \"windows\": %d, \"trials\": %d, "
+                     "\"trials_aborted\": %d, \"switches\": %d, \"outliers\": %d}", d ? ", " : "", d, st.frames[0], st.frames[1], st.windows, st.trials,
+                     st.trials_aborted, st.switches, st.outliers);
+            choice += buf;
+        }
+        choice += "]";
+    }
     printf("{\"frames\": %d, \"width\": %d, \"height\": %d, \"n_gpus\": %d, \"seconds\": %.4f, \"fps\": %.3f, \"Mrays_per_s\": %.3f, "
            "\"path\": \"%s\", \"spin\": %g, \"arith_mode\": \"%s\", \"noise_tables\": {\"builds\": %d, \"table_frames\": %d, "
-           "\"arith_frames\": %d, \"coarsest_coverage\": %d, \"peak_bytes\": %zu, \"budget_bytes\": %zu}, \"tile_order\": %s, \"collective\": \"%s\"}\n",
-           frames, w, h, gpus, dt, frames / dt, (double)frames * w * h / dt / 1e6, path_name, spin, fast ? "fast" : "strict",
+           "\"arith_frames\": %d, \"coarsest_coverage\": %d, \"peak_bytes\": %zu, \"budget_bytes\": %zu}, \"tile_order\": %s, \"collective\": \"%s\", "
+           "\"path_choice\": %s}\n",
+           frames, w, h, gpus, dt, frames / dt, (double)frames * w * h / dt / 1e6, path_name, spin,
+           arith == RRT_ARITH_FAST ? "fast" : (arith == RRT_ARITH_FMAD ? "fmad" : "strict"),
            table_builds, table_frames, arith_frames, coarsest, table_peak, table_budget, dev[0].order[0] ? "true" : "false",
-           collective ? "rccl grouped send/recv gather" : "none");
+           collective ? "rccl grouped send/recv gather" : "none", choice.c_str());
 
     for (int d = 0; d < gpus; ++d) {
         Device& D = dev[d];
@@ -461,6 +510,7 @@ int main(int argc, char** argv) {
         if (D.comm) ncclCommDestroy(D.comm);
         (void)hipFree(D.probe);
         (void)hipEventDestroy(D.comm_free);
+        if (D.chooser) { rrt_path_chooser_destroy(D.chooser); for (int e = 0; e < 2 * kSlots; ++e) (void)hipEventDestroy(D.render_end[e]); }
         for (int s = 0; s < kSlots; ++s) {
             if (D.pool[s]) rrt_workspace_destroy(D.pool[s]);
             if (D.order[s]) rrt_tile_order_destroy(D.order[s]);

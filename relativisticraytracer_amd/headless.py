@@ -26,7 +26,13 @@ def main(argv=None):
     ap.add_argument("--spin", type=float, default=0.0)          # SPIN_A, config.h:21
     ap.add_argument("--path", type=int, default=-1, help="built-in camera path 0..2; -1 = fixed start-up camera")
     ap.add_argument("--no-volumetrics", action="store_true")
-    ap.add_argument("--fast", action="store_true", help="RRT_ARITH_FAST (not the parity path)")
+    ap.add_argument("--fast", action="store_true", help="RRT_ARITH_FAST (not the parity path); = --arith fast")
+    ap.add_argument("--arith", choices=("strict", "fmad", "fast"), default=None,
+                    help="arithmetic of the RK4 step: strict (default; bit-identical to the oracle), fmad (multiply-adds fused, roots and "
+                         "divisions correctly rounded: the class of the reference's nvcc-default build), fast (also 1-ulp rsq)")
+    ap.add_argument("--path-window", type=int, default=0,
+                    help="several frames in flight, a share under the three-pass threshold: frames per window of the per-rank path choice "
+                         "(rrt_path_chooser; 0 = 48); -1: no choice, the three-pass path throughout")
     ap.add_argument("--all-effects", action="store_true", help="also enable chromatic aberration (key C)")
     ap.add_argument("--sky", default=None, help="equirectangular image file; default: synthetic sky, seed 1")
     ap.add_argument("--tile-rows", type=int, default=16)
@@ -109,9 +115,16 @@ def main(argv=None):
     three_pass_likely = bool(pools) and my_rays <= rrt._lib.load().rrt_path_auto_max_rays()      # RRT_PATH_AUTO's own threshold
     use_order = args.tile_order == "on" or (args.tile_order == "auto" and n_slots == 1 and not three_pass_likely)
     orders = [rrt.TileOrder() for _ in range(n_slots)] if use_order else []
+    arith_name = args.arith or ("fast" if args.fast else "strict")
+    arith_mode = {"strict": 0, "fast": 1, "fmad": 2}[arith_name]
+    # the path of a small share under frames in flight is chosen per window by measurement (sharding.PathChooser; the rule and the
+    # numbers behind it: csrc/rrt_path_chooser.cpp); RRT_PATH_POLICY pins it
+    chooser = (sharding.PathChooser(n_slots, args.path_window)
+               if (args.path_window >= 0 and n_slots >= 2 and three_pass_likely and "RRT_PATH_POLICY" not in os.environ) else None)
+    ends = {}                      # frame -> the event at the end of its render on this rank
     prms = [rrt.RenderParams(spin=args.spin, volumetrics=0 if args.no_volumetrics else 1,
                              noise_table=0, tile_order=orders[j].id if orders else 0,
-                             arith_mode=1 if args.fast else 0, workspace=pools[j].id if pools else 0,
+                             arith_mode=arith_mode, workspace=pools[j].id if pools else 0,
                              # frames in flight fill each other's drains: ONE chain per launch (the second chain's streams only compete with
                              # the other frames: 2-7 % per frame, profiles/r05_sustained_chains.txt).  The plain single kernel would be
                              # faster still on most views (0.98-1.0 of a rank's fair share against 0.86-0.96) but its longest wavefront
@@ -120,11 +133,25 @@ def main(argv=None):
                              pass_chains=1 if n_slots >= 2 else 0,
                              path_policy=int(os.environ.get("RRT_PATH_POLICY", "0"))) for j in range(n_slots)]
     path = camera_paths.CameraPath(args.path) if args.path >= 0 else None
-    state = {"t": 0.0, "cam": rrt.CameraState.default(), "table": 0}
+    state = {"t": 0.0, "cam": rrt.CameraState.default(), "table": 0, "k": 0}
 
     def render(buf, slot):
         prms[slot].noise_table = state["table"]
+        k = state["k"]
+        if chooser is not None:
+            prms[slot].path_policy = chooser.policy(k)
         rrt.launch_raymarch_tiles(buf, w, h, args.tile_rows, rank, world, state["t"], state["cam"], tex, fx, prms[slot])
+        if chooser is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()                                        # on the slot's stream (FrameSharder runs the callback inside it)
+            ends[k] = e
+            # sustained time of the frames that have finished since: the interval between consecutive frames' render ends
+            for j in sorted(ends):
+                if j - 1 in ends and ends[j].query() and ends[j - 1].query():
+                    # (a frame that ends BEFORE its predecessor -- the predecessor holds a long wavefront -- reports 0; the
+                    # predecessor's own interval is then the long one, which is what the outlier rule looks for)
+                    chooser.report(j, max(0.0, ends[j - 1].elapsed_time(ends[j])))
+                    del ends[j - 1]
 
     def assemble(frame, buf, shard):
         rrt.assemble_tiles(frame, buf, w, h, args.tile_rows, shard, world)
@@ -149,6 +176,7 @@ def main(argv=None):
         dog.arm(args.frame_timeout + (args.init_timeout if k == 1 else 0.0), f"frame {k}")    # frame 1 brings the communicator's channels up
         sim_t, path_t = camera_paths.recording_clock(k, args.fps)
         state["t"] = sim_t
+        state["k"] = k
         state["table"] = nwin.table_id(sim_t)
         if path is not None:
             state["cam"] = path.camera_at(path_t)
@@ -171,12 +199,15 @@ def main(argv=None):
         print(json.dumps({"frames": args.frames, "width": w, "height": h, "n_gpus": world, "seconds": round(dt, 4),
                           "fps": round(args.frames / dt, 3), "Mrays_per_s": round(args.frames * w * h / dt / 1e6, 3),
                           "path": path.name if path else None, "spin": args.spin,
-                          "arith_mode": "fast" if args.fast else "strict", "sink": args.out,
+                          "arith_mode": arith_name, "sink": args.out,
+                          "path_choice": chooser.stats() if chooser else None,
                           "noise_tables": nwin.summary(),
                           "tile_order": orders[0].info() if orders else None}), flush=True)
     if world > 1:
         dist.destroy_process_group()
     nwin.close()
+    if chooser is not None:
+        chooser.destroy()
     for o in orders:
         o.destroy()
     tex.destroy()

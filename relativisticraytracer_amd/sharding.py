@@ -150,6 +150,43 @@ def init_process_group(backend, rank, world, device=None, timeout_s=300.0):
     return dist
 
 
+class PathChooser:
+    """Which path this rank's share takes while several frames of a sequence are in flight (include/rrt.h: rrt_path_chooser_*;
+    the rule lives in csrc/rrt_path_chooser.cpp, the C++ headless driver uses the same object).  Host logic only.
+
+        pc = PathChooser(frames_in_flight)
+        per frame k = 1, 2, ...:   prm.path_policy = pc.policy(k)  ...  later, when known:  pc.report(k, sustained_ms)
+    """
+
+    def __init__(self, frames_in_flight, window_frames=0):
+        import ctypes as C
+        from . import _lib
+        self._lib, self._C = _lib, C
+        out = C.c_int(0)
+        _lib.check(_lib.load().rrt_path_chooser_create(int(frames_in_flight), int(window_frames), C.byref(out)), "rrt_path_chooser_create")
+        self.id = out.value
+
+    def policy(self, frame):
+        p = self._C.c_int(0)
+        self._lib.check(self._lib.load().rrt_path_chooser_policy(self.id, int(frame), self._C.byref(p)), "rrt_path_chooser_policy")
+        return p.value
+
+    def report(self, frame, sustained_ms):
+        self._lib.check(self._lib.load().rrt_path_chooser_report(self.id, int(frame), float(sustained_ms)), "rrt_path_chooser_report")
+
+    def stats(self):
+        st = self._lib.rrt_path_chooser_stats()
+        self._lib.check(self._lib.load().rrt_path_chooser_get_stats(self.id, self._C.byref(st)), "rrt_path_chooser_get_stats")
+        return {"incumbent": "single kernel" if st.incumbent == 1 else "automatic (three-pass for a small share)", "windows": st.windows,
+                "trials": st.trials, "trials_aborted": st.trials_aborted, "switches": st.switches, "outliers": st.outliers,
+                "frames_three_pass_auto": st.frames[0], "frames_single_kernel": st.frames[1]}
+
+    def destroy(self):
+        if self.id:
+            self._lib.load().rrt_path_chooser_destroy(self.id)
+            self.id = 0
+
+
 class FrameSharder:
     """One rank's view of a sharded frame.
 

@@ -241,6 +241,44 @@ def test_two_ranks_pipelined_equal_one_rank(tmp_path):
 
 
 @pytest.mark.gpu
+def test_path_choice_changes_no_byte(tmp_path):
+    """Round 6: under frames in flight a small share's path is chosen per window by measurement (rrt_path_chooser).  40 frames
+    of path 0 through the C++ driver -- a single device with the exchange, and without -- and through two ranks of the Python
+    driver sharing the card: with trials of the single kernel (windows of 18 frames, so that three trials fit) the bytes are
+    those of the three-pass-only run (--path-window -1), and the summary line says which path rendered how many frames."""
+    import socket
+    from relativisticraytracer_amd import build
+    exe = build.build_headless()
+    base = ["--width", "160", "--height", "90", "--frames", "40", "--path", "0", "--spin", "0.9", "--workspace-gib", "1"]
+    want = tmp_path / "want.rgba"
+    r = subprocess.run([exe] + base + ["--path-window", "-1", "--out", str(want)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["path_choice"] is None
+    for extra in (["--path-window", "18"], ["--path-window", "18", "--force-collective"], ["--path-window", "18", "--frames-in-flight", "2"]):
+        out = tmp_path / "got.rgba"
+        r = subprocess.run([exe] + base + extra + ["--out", str(out)], capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        pc = json.loads(r.stdout.strip().splitlines()[-1])["path_choice"]
+        assert len(pc) == 1 and pc[0]["frames_three_pass"] + pc[0]["frames_single_kernel"] == 40
+        assert pc[0]["trials"] >= 1 and pc[0]["frames_single_kernel"] >= 3, pc
+        assert open(out, "rb").read() == open(want, "rb").read(), extra
+    # one frame at a time: nothing to choose (the three-pass path's two chains are the answer there)
+    r = subprocess.run([exe] + base + ["--frames-in-flight", "1"], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["path_choice"] is None
+    env = dict(os.environ, RRT_DIST_BACKEND="gloo")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = tmp_path / "py2.rgba"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        "-m", "relativisticraytracer_amd.headless"] + base + ["--path-window", "18", "--out", str(out)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    meta = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert meta["n_gpus"] == 2 and meta["path_choice"]["trials"] >= 1 and meta["path_choice"]["frames_single_kernel"] >= 3
+    assert open(out, "rb").read() == open(want, "rb").read()
+
+
+@pytest.mark.gpu
 def test_bench_line_contract():
     """bench.py at a reduced frame size: one JSON line with the driver's keys, the roofline and the CPU baseline."""
     r = subprocess.run([sys.executable, "bench.py", "--width", "320", "--height", "180", "--steps", "2", "--warmup", "1",

@@ -1,0 +1,83 @@
+"""The per-window path choice of the animation drivers (include/rrt.h: rrt_path_chooser_*, csrc/rrt_path_chooser.cpp):
+host logic only -- runs without a GPU.  A synthetic rank reports sustained frame times of the two paths with the lag the
+drivers have (a frame's time is known `frames in flight` frames after it was enqueued)."""
+import random
+
+import pytest
+
+
+def drive(single_ms, three_pass_ms, frames=400, slots=3, window=0, noise=0.03, seed=1):
+    from relativisticraytracer_amd.sharding import PathChooser
+    rnd = random.Random(seed)
+    pc = PathChooser(slots, window)
+    total, pend, pol = 0.0, [], []
+    for k in range(1, frames + 1):
+        p = pc.policy(k)
+        pol.append(p)
+        ms = (single_ms(k) if p == 1 else three_pass_ms(k)) * (1.0 + rnd.uniform(-noise, noise))
+        total += ms
+        pend.append((k, ms))
+        if len(pend) > slots:
+            pc.report(*pend.pop(0))
+    st = pc.stats()
+    pc.destroy()
+    return total / frames, st, pol
+
+
+def test_first_window_measures_the_three_pass_path_then_trials_start():
+    _, st, pol = drive(lambda k: 5.0, lambda k: 5.0, frames=60)
+    assert pol[:10] == [0] * 10                      # 2 * frames in flight + 4 frames, no trial
+    assert pol[10:16] == [1] * 6                     # the second window opens with the trial: frames in flight + 3 frames
+    assert st["trials"] >= 1 and st["frames_single_kernel"] >= 6
+
+
+def test_keeps_the_single_kernel_where_it_sustains_faster_frames():
+    """bench-like share (profiles/r05_sustained_chains.txt: 4.56 against 4.74 ms): within 1 % of the better path."""
+    mean, st, _ = drive(lambda k: 4.56, lambda k: 4.74)
+    assert st["incumbent"] == "single kernel" and st["switches"] == 1 and st["outliers"] == 0
+    assert mean <= 4.56 * 1.012 and st["frames_single_kernel"] >= 280
+
+
+def test_a_long_wavefront_ends_the_experiment_at_once():
+    """grazing share: single-kernel frames at 7.5 ms with every fifth at 19 (a slot waits for one long wavefront) against the
+    three-pass path's flat 6.2: the single kernel is tried, dropped on the first slow frame, tried again ever more rarely."""
+    mean, st, pol = drive(lambda k: 7.5 if k % 5 else 19.0, lambda k: 6.2)
+    assert st["incumbent"].startswith("automatic") and st["switches"] == 0
+    assert st["trials_aborted"] == st["trials"] >= 2 and st["outliers"] >= st["trials_aborted"]
+    assert st["frames_single_kernel"] <= 24 and mean <= 6.2 * 1.03          # the price of looking: < 3 %
+    gaps = [i for i in range(1, len(pol)) if pol[i] == 1 and pol[i - 1] == 0]
+    assert all(b - a >= 90 for a, b in zip(gaps, gaps[1:]))                   # back-off: the next trial two windows later, then four
+
+
+def test_a_single_kernel_that_turns_slow_is_found_within_a_window():
+    mean, st, pol = drive(lambda k: 6.2 if k < 200 else 9.0, lambda k: 6.6)
+    assert st["switches"] == 2 and st["incumbent"].startswith("automatic")
+    assert sum(pol[199 + 100:]) <= 12                # a hundred frames after the change the three-pass path has taken over
+    assert mean <= 6.4 * 1.08                        # ideal: 6.2 then 6.6
+
+
+def test_the_incumbent_single_kernel_is_demoted_by_an_outlier_before_its_window_ends():
+    _, st, pol = drive(lambda k: 5.8 if k < 150 else (7.5 if k % 7 else 19.0), lambda k: 6.2)
+    assert st["incumbent"].startswith("automatic") and st["outliers"] >= 1
+    assert sum(pol[150 + 20:150 + 48]) == 0          # within 20 frames of the first slow frame the rest of the window is three-pass
+
+
+def test_no_preference_without_a_difference():
+    _, st, _ = drive(lambda k: 6.0, lambda k: 6.0)
+    assert st["switches"] == 0 and st["incumbent"].startswith("automatic")   # hysteresis: 3 % or nothing
+
+
+def test_arguments_and_handles():
+    import ctypes as C
+    from relativisticraytracer_amd import _lib
+    lib = _lib.load()
+    out = C.c_int(0)
+    assert lib.rrt_path_chooser_create(0, 0, C.byref(out)) == 1                # RRT_ERR_INVALID_ARGUMENT
+    assert lib.rrt_path_chooser_create(3, 0, None) == 1
+    assert lib.rrt_path_chooser_create(3, 4, C.byref(out)) == 0               # a window too short for two trials' worth is widened
+    p = C.c_int(-1)
+    assert lib.rrt_path_chooser_policy(out.value, 0, C.byref(p)) == 1
+    assert lib.rrt_path_chooser_policy(out.value, 1, C.byref(p)) == 0 and p.value == 0
+    assert lib.rrt_path_chooser_report(out.value, 1, float("nan")) == 1 and lib.rrt_path_chooser_report(out.value, 1, 5.0) == 0
+    assert lib.rrt_path_chooser_destroy(out.value) == 0
+    assert lib.rrt_path_chooser_destroy(out.value) == 4 and lib.rrt_path_chooser_policy(out.value, 2, C.byref(p)) == 4   # RRT_ERR_BAD_HANDLE
