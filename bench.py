@@ -43,7 +43,7 @@ def source_hash():
     it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("rrt_hip.hip", "rrt_kernels.h", "rrt_device.h", "rrt_math.h", "rrt_tile_sort.h"):
+    for f in ("rrt_hip.hip", "rrt_kernels.h", "rrt_device.h", "rrt_math.h", "rrt_tile_sort.h", "rrt_noise_plan.h", "rrt_tile_objects.h"):
         h.update(open(os.path.join(ROOT, "relativisticraytracer_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -717,7 +717,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{w}x{h} Kerr a={args.spin:g} full volumetric disk+dust, default camera "
                                    f"(0,10,-60) yaw 0 pitch -10, t=1.0, default effects, synthetic 2048x1024 sky seed 1",
-                       "rays_per_frame": rays, "max_steps": 2000, "arith_mode": "strict (bit-exact vs oracle)",
+                       "rays_per_frame": rays, "max_steps": 2000, "arith_mode": "strict (byte-identical to the CPU restatement of the reference; vs the reference's own kernel body compiled by g++: step counts identical, <= 1 LSB on <= 1e-4 of the bytes)",
                        "parallelism": (f"rowtiles{R}x{world}" + (", %d frames in flight (the next renders overlap gather/assemble of frame k)" % fs.n_slots if fs.pipeline else ""))
                                       if world > 1 else "single",
                        "path": ("auto: three-pass below 1.5 M rays per launch, %d GiB pool" % args.workspace_gib) if ws else "single kernel",

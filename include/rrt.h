@@ -230,6 +230,9 @@ int rrt_workspace_read(int id, size_t offset, size_t bytes, void* host_dst);
  *      CAPTURED into a hipGraph ignores the object (static order, nothing recorded): a replayed graph can then never read
  *      a permutation that a later live launch is rewriting.  Works on both paths (single kernel and three-pass). ---- */
 int rrt_tile_order_create(int* out_id);
+/* Must be called with the device that owns the object CURRENT (the one that was current at create): under another device it
+ * returns RRT_ERR_BAD_HANDLE and frees NOTHING -- the handle stays valid and the call can be repeated from the right device
+ * (rrt_tile_map_destroy: the same rule).  A caller that ignores the status there leaks the object's device buffers. */
 int rrt_tile_order_destroy(int id);
 int rrt_tile_order_set_seeding(int id, int on);
 int rrt_tile_order_seeded(int id, unsigned long long* seeded_launches);      /* launches ordered by the probe */
@@ -295,6 +298,18 @@ int rrt_clock_probe(unsigned long long* d_counters2, unsigned duration_us, void*
  *      no argument for them: spin, max_steps, volumetrics, a workspace, a noise table ...  NULL restores the
  *      config.h defaults.  Nothing is allocated on the caller's behalf: objects named here are the caller's. ---- */
 int rrt_set_launch_defaults(const rrt_params* prm);
+/* ---- ... or, in ONE call, let the library own them (round 6).  For a host that makes only the drop-in edits and keeps calling
+ *      launch_raymarch(): rrt_launch_auto_resources(1, base, table_budget_bytes, pool_bytes) creates ON THE CURRENT DEVICE a pool
+ *      (pool_bytes; 0: none), a tile order and -- lazily, at the first launch -- lattice-hash tables over a window of `time` that fits
+ *      table_budget_bytes (0: none), and every launch_raymarch() under that device then runs with `base` (NULL: config.h; its
+ *      spin, max_steps, arith_mode ... are kept, its object fields replaced) + those objects: same bytes, the full speed of the
+ *      path.  THE DOCUMENTED EXCEPTION to "a launch allocates nothing": the launch_raymarch() call whose `time` has left the table's
+ *      window (the reference's simTime grows without bound, main.cpp:515) waits for the device, destroys the table and builds the
+ *      next window (milliseconds) before it launches.  Calls under another current device use the plain defaults above.
+ *      rrt_launch_auto_resources(0, NULL, 0, 0), from the same device, destroys everything.  Explicit rrt_launch_raymarch*()
+ *      calls are never affected. ---- */
+int rrt_launch_auto_resources(int on, const rrt_params* base, size_t table_budget_bytes, size_t pool_bytes);
+int rrt_launch_auto_resources_info(int* on, int* table_builds, float* table_t0, float* table_t1, size_t* table_bytes);   /* any pointer may be NULL */
 int rrt_get_launch_defaults_sized(void* out, uint32_t size);        /* through the macro: size = the caller's sizeof(rrt_params) */
 #define rrt_get_launch_defaults(out) rrt_get_launch_defaults_sized((out), (uint32_t)sizeof(rrt_params))
 /* launch_raymarch() with plain C types (what both C++ symbols of that name forward to): cam12 = pos, forward,

@@ -214,7 +214,9 @@ class TileOrder:
 
     def destroy(self):
         if getattr(self, "id", 0):
-            _lib.load().rrt_tile_order_destroy(self.id)
+            # the object must be destroyed under the device that owns it (include/rrt.h); a refused destroy frees nothing and keeps
+            # the handle valid, so the status is NOT ignored here: the wrapper keeps its id and the caller hears of it
+            _lib.check(_lib.load().rrt_tile_order_destroy(self.id), "rrt_tile_order_destroy")
             self.id = 0
 
     def __del__(self):
@@ -248,7 +250,7 @@ class TileMap:
 
     def destroy(self):
         if getattr(self, "id", 0):
-            _lib.load().rrt_tile_map_destroy(self.id)
+            _lib.check(_lib.load().rrt_tile_map_destroy(self.id), "rrt_tile_map_destroy")      # as TileOrder.destroy
             self.id = 0
 
     def __del__(self):

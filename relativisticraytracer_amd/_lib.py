@@ -101,6 +101,8 @@ SYMBOLS = [
     ("rrt_noise_table_plan_layout", _i, [_f, _f, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f), _vp, _i, _vp]),
     ("rrt_noise_table_fit_window", _i, [_f, _f, C.c_size_t, C.POINTER(_f), C.POINTER(_i), C.POINTER(C.c_size_t)]),
     ("rrt_set_launch_defaults", _i, [_prm]),
+    ("rrt_launch_auto_resources", _i, [_i, _prm, C.c_size_t, C.c_size_t]),
+    ("rrt_launch_auto_resources_info", _i, [C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_size_t)]),
     ("rrt_get_launch_defaults_sized", _i, [_vp, C.c_uint32]),
     ("rrt_launch_raymarch_compat", _i, [_vp, _i, _i, _f, C.POINTER(C.c_float * 12), _ull, _vp]),
     ("rrt_workspace_stats", _i, [_i, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),

@@ -20,7 +20,7 @@ SOURCES = [os.path.join(CSRC, "rrt_hip.hip")]
 COMPAT_SRC = os.path.join(CSRC, "rrt_compat.cpp")     # launch_raymarch under the reference's mangled name (host only, g++)
 CAMERA_SRC = os.path.join(CSRC, "rrt_camera.cpp")     # camera basis / path playback (host only, g++)
 CHOOSER_SRC = os.path.join(CSRC, "rrt_path_chooser.cpp")   # per-window path choice of the animation drivers (host only, g++)
-HEADERS = [os.path.join(CSRC, f) for f in ("rrt_device.h", "rrt_math.h", "rrt_tile_sort.h", "rrt_kernels.h", "rrt_test_hooks.h")] + [
+HEADERS = [os.path.join(CSRC, f) for f in ("rrt_device.h", "rrt_math.h", "rrt_tile_sort.h", "rrt_kernels.h", "rrt_test_hooks.h", "rrt_noise_plan.h", "rrt_tile_objects.h")] + [
     COMPAT_SRC, CAMERA_SRC, CHOOSER_SRC, os.path.join(PKG, "..", "include", "rrt.h"), os.path.join(PKG, "..", "include", "rrt_test.h"),
     os.path.join(PKG, "..", "include", "raymarcher.h")]
 
@@ -64,35 +64,38 @@ def host_objects(outdir):
 
 
 def build_lib(force=False, extra_flags=(), verbose=False):
-    """librrt_hip.so (the product) and librrt_hip_test.so (+ test hooks), from the same sources; the two hipcc compiles run
-    side by side."""
+    """librrt_hip.so (the product) and librrt_hip_test.so (+ test hooks), from the same sources.  Each hipcc compile runs in a
+    directory of its own (lib/_obj_product, lib/_obj_test: flags that write fixed-name side files -- -save-temps -- cannot make
+    the two collide); they run side by side, except under -save-temps, where they run one after the other.  BOTH libraries are
+    always built, so that is_stale() has one meaning."""
     if not force and not is_stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     host_objs = host_objects(LIBDIR)
     # two steps per library: with a .hip input hipcc compiles every input as HIP source, objects included
     base = [hipcc_path()] + [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
+    sequential = "-save-temps" in extra_flags
+    todo = ((LIB, "product", []), (TEST_LIB, "test", ["-DRRT_TEST_HOOKS"]))
     jobs = []
-    for obj, defs in ((os.path.join(LIBDIR, "rrt_hip.o"), []), (os.path.join(LIBDIR, "rrt_hip_test.o"), ["-DRRT_TEST_HOOKS"])):
-        cmd = base + defs + ["-c"] + SOURCES + ["-o", obj]
+    for lib, tag, defs in todo:
+        wd = os.path.join(LIBDIR, "_obj_" + tag)
+        os.makedirs(wd, exist_ok=True)
+        cmd = base + defs + ["-c"] + SOURCES + ["-o", os.path.join(wd, "rrt_hip.o")]
         if verbose:
             print(" ".join(cmd), flush=True)
-        if "-save-temps" in extra_flags:       # temporaries of the two compiles would collide: product only, one at a time
-            if defs:
-                continue
-            subprocess.run(cmd, check=True, cwd=LIBDIR)
+        if sequential:
+            subprocess.run(cmd, check=True, cwd=wd)
         else:
-            jobs.append((cmd, subprocess.Popen(cmd, cwd=LIBDIR)))
+            jobs.append((cmd, subprocess.Popen(cmd, cwd=wd)))
     for cmd, pr in jobs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    for lib, obj in ((LIB, os.path.join(LIBDIR, "rrt_hip.o")), (TEST_LIB, os.path.join(LIBDIR, "rrt_hip_test.o"))):
-        if not os.path.exists(obj) or ("-save-temps" in extra_flags and lib == TEST_LIB):
-            continue
-        link = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", obj] + host_objs + ["-o", lib]
+    for lib, tag, defs in todo:
+        wd = os.path.join(LIBDIR, "_obj_" + tag)
+        link = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", os.path.join(wd, "rrt_hip.o")] + host_objs + ["-o", lib]
         if verbose:
             print(" ".join(link), flush=True)
-        subprocess.run(link, check=True, cwd=LIBDIR)
+        subprocess.run(link, check=True, cwd=wd)
     return LIB
 
 

@@ -85,3 +85,61 @@ def test_reference_header_object_renders_the_same_frame():
         build_ref_header_main()
     out = subprocess.run([REF_EXE, "64", "36"], check=True, capture_output=True, text=True).stdout.split()
     assert out[-1] == _python_checksum()
+
+
+@pytest.mark.gpu
+def test_auto_resources_give_the_drop_in_entry_point_its_speed_and_the_same_bytes(sky):
+    """Round 6: a host that keeps calling the reference-signature launch_raymarch() gets pool, tile order
+    and noise tables from ONE call, rrt_launch_auto_resources -- library-owned, the tables sliding along `time` -- and renders the
+    bytes of an explicit launch with caller-owned objects (and of a launch with none).  Checked through rrt_launch_raymarch_compat,
+    the C body of both C++ launch_raymarch symbols."""
+    import ctypes as C
+    import torch
+    import relativisticraytracer_amd as rrt
+    from relativisticraytracer_amd import _lib
+    lib = _lib.load()
+    tex = rrt.SkyTexture(sky)
+    w, h = 320, 180
+    cam = rrt.CameraState.from_angles((15.0, 3.0, -30.0), -20.0, -5.0)
+    fx = rrt.CameraEffects()
+    cam12 = (C.c_float * 12)(*cam.as_array().reshape(-1).tolist())
+    out = torch.zeros(h * w * 4, dtype=torch.uint8, device="cuda")
+    want = torch.zeros_like(out)
+    on, builds, t0, t1, nbytes = C.c_int(0), C.c_int(0), C.c_float(0), C.c_float(0), C.c_size_t(0)
+
+    def info():
+        assert lib.rrt_launch_auto_resources_info(C.byref(on), C.byref(builds), C.byref(t0), C.byref(t1), C.byref(nbytes)) == 0
+        return on.value, builds.value, t0.value, t1.value, nbytes.value
+
+    base = rrt.RenderParams(spin=0.9)
+    try:
+        assert info()[0] == 0
+        _lib.check(lib.rrt_launch_auto_resources(1, C.byref(base), 96 << 20, 256 << 20), "rrt_launch_auto_resources")
+        assert info()[:2] == (1, 0)                                   # tables are built lazily, at the first launch
+        seen = []
+        # 96 MB hold [t, t + 120] at the coarsest coverage near the origin of the clock and nothing at t = 400: the window slides
+        # once (t = 130), and the last launch remembers "nothing fits" and hashes arithmetically -- same bytes throughout
+        for t in (1.0, 1.5, 130.0, 131.0, 400.0):
+            rrt.launch_raymarch(want, w, h, t, cam, tex, fx, rrt.RenderParams(spin=0.9))
+            out.zero_()
+            _lib.check(lib.rrt_launch_raymarch_compat(C.c_void_p(out.data_ptr()), w, h, C.c_float(t), C.byref(cam12), tex.handle, C.byref(fx)),
+                       "rrt_launch_raymarch_compat")
+            torch.cuda.synchronize()
+            assert torch.equal(out, want), t
+            seen.append(info())
+            assert seen[-1][2] <= t <= seen[-1][3]
+        assert [s[1] for s in seen] == [1, 1, 2, 2, 2] and seen[0][4] > 0 and seen[2][4] > 0 and seen[4][4] == 0      # one build per window
+        # explicit launches are not affected, and switching off destroys everything
+        _lib.check(lib.rrt_launch_auto_resources(0, None, 0, 0), "rrt_launch_auto_resources(0)")
+        assert info()[0] == 0
+        out.zero_()
+        _lib.check(lib.rrt_launch_raymarch_compat(C.c_void_p(out.data_ptr()), w, h, C.c_float(1.0), C.byref(cam12), tex.handle, C.byref(fx)), "compat")
+        rrt.launch_raymarch(want, w, h, 1.0, cam, tex, fx, rrt.RenderParams())         # config.h defaults again: spin 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+        bad = rrt.RenderParams(spin=0.9); bad.struct_size = 40
+        assert lib.rrt_launch_auto_resources(1, C.byref(bad), 0, 0) == 6                # RRT_ERR_ABI_MISMATCH, nothing created
+        assert info()[0] == 0
+    finally:
+        lib.rrt_launch_auto_resources(0, None, 0, 0)
+        tex.destroy()

@@ -1119,8 +1119,15 @@ def test_handles_are_tied_to_their_device(ctx, sky):
             assert lib.rrt_tile_order_info(order.id, None, None, None, None, None, 0) == 4
             prm = rrt.RenderParams(spin=0.9, tile_order=order.id)
             assert lib.rrt_launch_raymarch(C.c_void_p(out.data_ptr()), w, h, 1.0, C.byref(a), sky2, C.byref(fx), C.byref(prm), None) == 4
+            # destroying a tile order (or tile map) from the wrong device is REFUSED and frees nothing (include/rrt.h): the raw call
+            # says RRT_ERR_BAD_HANDLE, the Python wrapper raises and keeps its id, and the object still works afterwards
+            assert lib.rrt_tile_order_destroy(order.id) == 4
+            with pytest.raises(rrt.RRTError) as e:
+                order.destroy()
+            assert e.value.status == 4 and order.id != 0
             lib.rrt_sky_destroy(sky2)
             lib.rrt_debug_fake_device(-1)
+            assert lib.rrt_tile_order_info(order.id, None, None, None, None, None, 0) == 0
             out.zero_()
             rrt.launch_raymarch(out, w, h, 1.0, cam, tex, fx, rrt.RenderParams(spin=0.9, noise_table=nt.id, workspace=ws.id, path_policy=2))
             torch.cuda.synchronize()
