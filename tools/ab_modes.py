@@ -1,3 +1,5 @@
+"""dev tool (GPU): the 4K bench frame timed in the three arithmetic modes (strict / FMAD / FAST), min and median of five frames, with a hash
+of the bytes; RRT_LIB_OVERRIDE A/Bs a variant build (tools/ab_modes_variants.py loops over lib/variants)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import relativisticraytracer_amd as rrt
