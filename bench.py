@@ -676,6 +676,23 @@ def main():
                     traffic_note = "profiles/hbm_traffic.json is from another build or workload; not used"
             except Exception:
                 traffic = None
+        # The counter view of the same kernel (rocprofv3 PMC, tools/pass_counters.sh): SQ_INSTS_VALU x 2 clocks / (1024 SIMDs x busy
+        # clocks) -- the share of all VALU issue slots the kernel filled; quoted only if measured on THIS build's kernel sources.
+        issue_util, issue_note = None, "not measured for this build: run tools/final_set.sh + tools/summarize_pass_counters.py"
+        ppath0 = os.path.join(ROOT, "profiles", "pass_counters.json")
+        if os.path.exists(ppath0) and world == 1 and (w, h) == (3840, 2160):
+            try:
+                pj0 = json.load(open(ppath0))
+                if pj0.get("source_hash") == source_hash():
+                    k0 = pj0.get("runs", {}).get("default/single", {}).get("raymarch_pixels")
+                    if k0:
+                        issue_util = k0.get("issue_slot_util")
+                        issue_note = ("rocprofv3 PMC, " + str(pj0.get("from", "profiles/")) + ": SQ_INSTS_VALU %.4g per launch x 2 clocks / (1024 SIMDs x "
+                                      "GRBM_GUI_ACTIVE / 8), %.2f ms under the profiler" % (k0.get("valu_insts") or 0.0, k0.get("ms_per_frame") or 0.0))
+                else:
+                    issue_note = "profiles/pass_counters.json is from another build; not used"
+            except Exception:
+                issue_util = None
         if heavy is not None and args.cpu_stride != 0:
             # per-ray work of the heavy view from a small oracle sample (exact counts, like the headline's)
             _, hm = cpu_baseline(w, h, args.spin, 96, sky_np, cam_arr=rrt.CameraState.from_angles((4.2, 0.6, 4.2), -90.0, -5.7).as_array(),
@@ -734,6 +751,7 @@ def main():
                                        "(boxes of this pool hold 2.2-2.4 GHz); > 1 is possible: the peak counts one SOURCE operation per lane and clock "
                                        "and the kernel needs 0.955 instructions per source operation",
                          "traffic_note": traffic_note,
+                         "issue_slot_util": issue_util, "issue_slot_util_note": issue_note,
                          "frac_of_fma_peak_157.3": round(tops / 157.3, 4),
                          "kernel": "raymarch_pixels", "kernel_ms": round(k_ms, 3), **k_stats,
                          "ops_per_ray": round(opr, 1), "per_ray_means": {k: round(v, 2) for k, v in means.items()},

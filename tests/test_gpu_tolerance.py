@@ -209,3 +209,35 @@ def test_fmad_deviates_less_than_a_contracted_reference(ctx, frames_ref, frames_
     print("total:", tot)
     for q in ("steps_differ", "off_by_more_than_1", "deviant", "bytes_differ"):
         assert tot["fmad"][q] <= tot["contracted"][q], (q, tot)
+
+
+def test_fmad_against_the_contracted_reference_on_the_bench_frame(ctx, po, sky):
+    """The same comparison at the size and view BASELINE's metric is quoted on (3840x2160, a = 0.9, the bench view), live: every 7th
+    pixel in x and y from the reference's kernel body compiled strictly and under contraction (oracle/_ref, where it travelled)
+    against the HIP FMAD and strict frames.  FMAD must not deviate more than the contracted reference does."""
+    if not (po.ref_frames_available() and po.ref_frames_fma_available()):
+        pytest.skip("oracle/_ref (the reference's kernel body, strict and contracted) did not travel with the tree")
+    import torch
+    rrt, tex, nt = ctx
+    w, h, stride, spin, t = 3840, 2160, 7, 0.9, 1.0
+    cam = rrt.CameraState.default()
+    ys = np.arange(0, h, stride); xs = np.arange(0, w, stride); rows = h - 1 - ys
+    fxo = po.default_effects()
+    ref = po.ref_render(cam.as_array(), fxo, spin, 1, t, w, h, sky, stride=(stride, stride))
+    con = po.ref_render(cam.as_array(), fxo, spin, 1, t, w, h, sky, stride=(stride, stride), fma=True)
+    ref8 = ref["rgba8"][np.ix_(rows, xs)].astype(int); ref_steps = ref["steps"].reshape(h, w)[np.ix_(ys, xs)]
+
+    def counts(rgba8, steps_topdown):
+        g8 = rgba8[np.ix_(rows, xs)].astype(int); gs = steps_topdown.reshape(h, w)[np.ix_(ys, xs)]
+        d = np.abs(g8 - ref8)[..., :3].max(axis=2)
+        return {"steps_differ": int((gs != ref_steps).sum()), "off_by_more_than_1": int((d > 1).sum()), "bytes_differ": int((d > 0).sum())}
+
+    rows_out = {"contracted": counts(con["rgba8"], con["steps"])}
+    for tag, mode in (("fmad", FMAD), ("strict", 0)):
+        F, steps, out = _frame(ctx, w, h, cam, t, spin=spin, arith_mode=mode)
+        rows_out[tag] = counts(out.cpu().numpy(), steps.flip(0).cpu().numpy())
+    print(f"4K bench view, every {stride}th pixel ({len(ys) * len(xs)} rays) against the strictly compiled reference: {rows_out}")
+    assert rows_out["strict"]["steps_differ"] == 0 and rows_out["strict"]["off_by_more_than_1"] == 0
+    for q in ("steps_differ", "off_by_more_than_1"):
+        assert rows_out["fmad"][q] <= rows_out["contracted"][q] + 3, (q, rows_out)
+    assert rows_out["fmad"]["bytes_differ"] <= rows_out["contracted"]["bytes_differ"] + rows_out["strict"]["bytes_differ"] + 3, rows_out

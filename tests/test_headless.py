@@ -241,6 +241,28 @@ def test_two_ranks_pipelined_equal_one_rank(tmp_path):
 
 
 @pytest.mark.gpu
+def test_both_drivers_render_the_same_fmad_frames(tmp_path):
+    """--arith fmad (round 6) through the C++ and the Python driver: the same bytes (FMAD is one function on every path), within a
+    handful of bytes of the strict frames, and the summary line names the mode."""
+    from relativisticraytracer_amd import build
+    exe = build.build_headless()
+    base = ["--width", "160", "--height", "90", "--frames", "3", "--path", "0", "--spin", "0.9"]
+    outs = {}
+    for tag, cmd in (("cpp_fmad", [exe] + base + ["--arith", "fmad"]), ("cpp_strict", [exe] + base),
+                     ("py_fmad", [sys.executable, "-m", "relativisticraytracer_amd.headless"] + base + ["--arith", "fmad"])):
+        out = tmp_path / (tag + ".rgba")
+        r = subprocess.run(cmd + ["--out", str(out)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        meta = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert meta["arith_mode"] == ("fmad" if "fmad" in tag else "strict")
+        outs[tag] = open(out, "rb").read()
+    assert outs["cpp_fmad"] == outs["py_fmad"]
+    diff = sum(a != b for a, b in zip(outs["cpp_fmad"], outs["cpp_strict"]))
+    assert diff <= 1e-3 * len(outs["cpp_strict"])         # (frames this small may not differ from the strict ones at all: ~1e-4 of the pixels do)
+    assert subprocess.run([exe] + base + ["--arith", "nvcc"], capture_output=True).returncode == 2
+
+
+@pytest.mark.gpu
 def test_path_choice_changes_no_byte(tmp_path):
     """Round 6: under frames in flight a small share's path is chosen per window by measurement (rrt_path_chooser).  40 frames
     of path 0 through the C++ driver -- a single device with the exchange, and without -- and through two ranks of the Python
