@@ -109,6 +109,29 @@ int main() {
     EXPECT(rrt_recording_clock(-1, 24, &st, &pt) != RRT_OK && rrt_recording_clock(1, 0, &st, &pt) != RRT_OK);
     EXPECT(rrt_recording_clock(3, 24, nullptr, nullptr) == RRT_OK);
 
+    // ---- per-window path choice (host logic only: csrc/rrt_path_chooser.cpp): three synthetic ranks, reports three frames late
+    {
+        int pc = 0, pol = -1;
+        EXPECT(rrt_path_chooser_create(0, 0, &pc) == RRT_ERR_INVALID_ARGUMENT && rrt_path_chooser_create(3, 0, nullptr) == RRT_ERR_INVALID_ARGUMENT);
+        EXPECT(rrt_path_chooser_policy(12345, 1, &pol) == RRT_ERR_BAD_HANDLE && rrt_path_chooser_report(12345, 1, 1.0f) == RRT_ERR_BAD_HANDLE);
+        for (int scenario = 0; scenario < 3; ++scenario) {
+            EXPECT(rrt_path_chooser_create(3, scenario == 2 ? 4 : 0, &pc) == RRT_OK);
+            float pend[3] = {0, 0, 0};
+            for (int k = 1; k <= 2500; ++k) {                              // beyond the policy ring's 1024 frames
+                EXPECT(rrt_path_chooser_policy(pc, k, &pol) == RRT_OK && (pol == RRT_PATH_AUTO || pol == RRT_PATH_SINGLE));
+                const float single = scenario == 0 ? 4.5f : (k % 5 ? 7.5f : 19.0f), three = scenario == 0 ? 4.8f : 6.2f;
+                if (k > 3) EXPECT(rrt_path_chooser_report(pc, k - 3, pend[k % 3]) == RRT_OK);
+                pend[k % 3] = pol == RRT_PATH_SINGLE ? single : three;
+            }
+            rrt_path_chooser_stats cs;
+            EXPECT(rrt_path_chooser_get_stats(pc, &cs) == RRT_OK && cs.frames[0] + cs.frames[1] == 2500 && cs.windows > 10);
+            EXPECT((scenario == 0) == (cs.incumbent == RRT_PATH_SINGLE));
+            EXPECT(rrt_path_chooser_report(pc, 0, 1.0f) == RRT_ERR_INVALID_ARGUMENT && rrt_path_chooser_report(pc, 5, NAN) == RRT_ERR_INVALID_ARGUMENT);
+            EXPECT(rrt_path_chooser_get_stats(pc, nullptr) == RRT_ERR_INVALID_ARGUMENT);
+            EXPECT(rrt_path_chooser_destroy(pc) == RRT_OK && rrt_path_chooser_destroy(pc) == RRT_ERR_BAD_HANDLE);
+        }
+    }
+
     // ---- shard arithmetic
     int rows = 0, total = 0;
     for (int s = 0; s < 8; ++s) { EXPECT(rrt_tile_shard_rows(2160, 16, s, 8, &rows) == RRT_OK); total += rows; }
@@ -125,6 +148,19 @@ int main() {
     EXPECT(rrt_set_launch_defaults(&prm) == RRT_ERR_INVALID_ARGUMENT);
     EXPECT(rrt_set_launch_defaults(nullptr) == RRT_OK && rrt_get_launch_defaults(&got) == RRT_OK && got.max_steps == 2000);
     EXPECT(rrt_get_launch_defaults(nullptr) == RRT_ERR_INVALID_ARGUMENT);
+
+    // ---- library-owned resources of the drop-in entry point: argument checks (nothing can be created without a device)
+    {
+        int on = -1, builds = -1; float t0 = 0, t1 = 0; size_t tb = 1;
+        EXPECT(rrt_launch_auto_resources_info(&on, &builds, &t0, &t1, &tb) == RRT_OK && on == 0 && builds == 0 && tb == 0);
+        EXPECT(rrt_launch_auto_resources_info(nullptr, nullptr, nullptr, nullptr, nullptr) == RRT_OK);
+        EXPECT(rrt_launch_auto_resources(0, nullptr, 0, 0) == RRT_OK);               // switching off what is off
+        rrt_params bad; rrt_params_default(&bad); bad.struct_size = 40;
+        EXPECT(rrt_launch_auto_resources(1, &bad, 0, 0) == RRT_ERR_ABI_MISMATCH);
+        rrt_params_default(&bad); bad.max_steps = -3;
+        EXPECT(rrt_launch_auto_resources(1, &bad, 0, 0) == RRT_ERR_INVALID_ARGUMENT);
+        EXPECT(rrt_launch_auto_resources_info(&on, nullptr, nullptr, nullptr, nullptr) == RRT_OK && on == 0);
+    }
 
     // ---- handles: unknown ids, argument checks, and the device binding (fake device ids: no GPU is touched)
     EXPECT(rrt_sky_destroy(0xdeadbeefull) == RRT_ERR_BAD_HANDLE);
