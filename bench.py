@@ -49,6 +49,7 @@ def source_hash():
 
 
 CPU_TARGET_S = 12.0       # wall seconds the timed CPU leg should last (>= 10 s: start-up and imbalance no longer show)
+CPU_MAX_RAYS = 2_200_000  # ... and never more rays than this (every 2nd pixel of the 4K frame), whatever the rate probe says
 
 
 def cpu_threads(world):
@@ -85,7 +86,10 @@ def cpu_sample_stride(width, height, spin, sky, nthreads=0):
                   want=("diag",), n_threads=nthreads or po.max_threads())
     dt = max(time.perf_counter() - t0, 1e-3)
     rate = (math.ceil(width / probe) * math.ceil(height / probe)) / dt
-    return max(1, int(math.floor(math.sqrt(width * height / max(rate * CPU_TARGET_S, 1.0)))))
+    stride = max(1, int(math.floor(math.sqrt(width * height / max(rate * CPU_TARGET_S, 1.0)))))
+    # The probe is short (a few hundredths of a second on 256 threads) and has been seen to overestimate the sustained rate five-fold
+    # (a 4-rank rehearsal: stride 1, 69 s of CPU leg): the sample is also capped at CPU_MAX_RAYS rays, 15-20 s at the rates seen so far.
+    return max(stride, int(math.ceil(math.sqrt(width * height / float(CPU_MAX_RAYS)))))
 
 
 def cpu_baseline(width, height, spin, stride, sky, cam_arr=None, time_=1.0, nthreads=0):
