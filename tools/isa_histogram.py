@@ -131,19 +131,65 @@ def analyse(src, name, pretty):
                 if cur_i >= len(blocks): break
         return path, seen
 
+    # Round 6: the vacuum steps run in a NESTED loop (rrt_kernels.h: vacuum_run), its body written out RRT_VAC_INNER times.  Its
+    # straight path: from the inner header until control returns to it; conditional branches fall through (rejected seeds, small
+    # radii, exits are the unlikely successors) EXCEPT a `s_cbranch_vccz` whose target is a stub of <= 2 instructions -- that is the
+    # "no lane is beyond r = 250" skip of the escape test's dot product, taken on all but a ray's last few steps.
+    inner = None
+    for b in blocks:
+        if re.search(r"Inner Loop Header: Depth=2", b["comment"]) and not b["label"].count("+"):
+            members = [x for x in blocks if x["label"].split("+")[0] == b["label"] or re.search(r"Header=%s Depth=2" % b["label"][2:], x["comment"])]
+            if sum(len(x["ins"]) for x in members) > 250 and any(VAC_LIT in t for x in members for t in x["ins"]):
+                inner = (b["label"], {x["label"] for x in members})
+    nested = []
+    if inner:
+        ihdr, ilabels = inner
+        first_of = {}
+        for k, bb in enumerate(blocks):
+            first_of.setdefault(bb["label"].split("+")[0], k)
+        cur_i, seen_i = order[ihdr], set()
+        while True:
+            b = blocks[cur_i]
+            if b["label"] in seen_i or b["label"] not in ilabels: break
+            seen_i.add(b["label"]); nested.append(b)
+            last = b["ins"][-1] if b["ins"] else ""
+            m = re.match(r"s_branch\s+(\.LBB\d+_\d+)", last)
+            mz = re.match(r"s_cbranch_vccz\s+(\.LBB\d+_\d+)", last)
+            if m:
+                if m.group(1) == ihdr: break
+                cur_i = order[m.group(1)]
+            elif mz and mz.group(1) in order and len(blocks[order[mz.group(1)]]["ins"]) <= 2 and not re.match(r"s_c?branch", (blocks[order[mz.group(1)]]["ins"] or [""])[-1]):
+                cur_i = order[mz.group(1)]
+            else:
+                cur_i += 1
+                if cur_i >= len(blocks): break
     straight, seen = walk(False)
     vacuum, vseen = walk(True) if vac_entry else ([], set())
+    if nested:
+        seen |= {b["label"] for b in nested}
     sideb = [b for b in loop if b["label"] not in seen and b["label"] not in vseen]
     print(f"== {pretty}")
     print(f"   registers: {res.get('NumVgprs')} VGPR, {res.get('TotalNumSgprs')} SGPR, occupancy {res.get('Occupancy')} waves/SIMD, "
           f"scratch {res.get('ScratchSize')} B, code {res.get('codeLenInByte')} B")
     sections = []
+    if nested:
+        m = re.search(r"#define RRT_VAC_INNER (\d+)", open(os.path.join(ROOT, "relativisticraytracer_amd", "csrc", "rrt_kernels.h")).read())
+        n_steps = int(m.group(1)) if m else 2
+        flags = os.environ.get("RRT_ISA_FLAGS", "")
+        mf = re.search(r"-DRRT_VAC_INNER=(\d+)", flags)
+        if mf: n_steps = max(1, int(mf.group(1)))
+        ins_n = [t.split()[0] for b in nested for t in b["ins"]]
+        valu_n = sum(1 for o in ins_n if o.startswith("v_"))
+        mov_n = sum(1 for o in ins_n if o.startswith("v_mov"))
+        print(f"   VACUUM LOOP (nested, body written out {n_steps}x): straight path {len(nested)} blocks, {len(ins_n)} instructions, {valu_n} VALU ({mov_n} v_mov) "
+              f"= {valu_n / n_steps:.1f} VALU per RK4 step")
+        sections.append((f"vacuum loop, straight path of one trip = {n_steps} RK4 steps (every lane at r >= 30: h = 0.3 folded, no zone tests)", nested))
     if vacuum and [b["label"] for b in vacuum] != [b["label"] for b in straight]:
         sections.append(("VACUUM path of the march loop (every lane at r >= 30: one RK4 step, h = 0.3 folded, no zone tests)", vacuum))
     sections.append(("generic path of the march loop (one RK4 step" + (", media blocks included" if len(loop) > 60 else "") + ")", straight))
     sections.append(("blocks of the loop off those paths (guarded fall-backs: rejected seeds, a stage radius < 1; lanes leaving)", sideb))
     if os.environ.get("RRT_ISA_DUMP") and os.environ["RRT_ISA_DUMP"] in pretty:      # the vacuum path's listing (or the generic one)
-        for b in (vacuum or straight):
+        for b in (nested or vacuum or straight):
             print("      " + b["label"])
             for t in b["ins"]:
                 print("         " + t)
