@@ -383,16 +383,17 @@ int rrt_launch_raymarch_ex(void* d_out_rgba8, int width, int height, float time,
  * New in this repo (the reference renders one frame at a time on one GPU: src/main.cpp:505-529).  A launch of <= 1.5 M rays
  * with a pool can take the three-pass path (RRT_PATH_AUTO) or the single kernel (RRT_PATH_SINGLE); under frames in flight the
  * single kernel is 3-10 % faster unless the share holds a wavefront that outlasts them (then 20 % slower).  The object cuts the
- * sequence into windows, tries the other path for a few frames at a window's start, compares SUSTAINED frame times (the
- * interval between the ends of consecutive frames' renders on the rank) and keeps the faster; a single-kernel frame that takes
- * > 1.5 x the three-pass median ends the experiment at once (csrc/rrt_path_chooser.cpp).  The bytes do not depend on it.
+ * sequence into windows, tries the other path for a few frames at a window's start, compares SUSTAINED frame times (the mean
+ * interval between the ends of consecutive frames' renders on the rank) and keeps the faster; frames_in_flight single-kernel
+ * frames in a row that take > 1.5 x the three-pass mean end the experiment at once (csrc/rrt_path_chooser.cpp).  The bytes do not
+ * depend on it.
  *   id = create(frames_in_flight, window_frames (0: 48));  per frame k = 1, 2, ...: policy(id, k, &p) -> rrt_params.path_policy;
  *   later, when frame k's times are known: report(id, k, ms). */
 typedef struct rrt_path_chooser_stats {
     int32_t incumbent;                 /* RRT_PATH_AUTO / RRT_PATH_SINGLE: what the current window renders with outside its trial */
     int32_t windows, trials, trials_aborted, switches, outliers;
     int32_t frames[2];                 /* frames handed to [0] the automatic (three-pass) path, [1] the single kernel */
-    float last_three_pass_median_ms;
+    float last_three_pass_mean_ms;
 } rrt_path_chooser_stats;
 int rrt_path_chooser_create(int frames_in_flight, int window_frames, int* out_id);
 int rrt_path_chooser_destroy(int id);

@@ -58,7 +58,7 @@ class rrt_debug_outputs(C.Structure):
 
 class rrt_path_chooser_stats(C.Structure):
     _fields_ = [("incumbent", C.c_int32), ("windows", C.c_int32), ("trials", C.c_int32), ("trials_aborted", C.c_int32),
-                ("switches", C.c_int32), ("outliers", C.c_int32), ("frames", C.c_int32 * 2), ("last_three_pass_median_ms", C.c_float)]
+                ("switches", C.c_int32), ("outliers", C.c_int32), ("frames", C.c_int32 * 2), ("last_three_pass_mean_ms", C.c_float)]
 
 
 # every symbol include/rrt.h declares: (name, restype, argtypes)

@@ -268,10 +268,11 @@ def test_path_choice_changes_no_byte(tmp_path):
     of path 0 through the C++ driver -- a single device with the exchange, and without -- and through two ranks of the Python
     driver sharing the card: with trials of the single kernel (windows of 18 frames, so that three trials fit) the bytes are
     those of the three-pass-only run (--path-window -1), and the summary line says which path rendered how many frames."""
+    # (a window holds at least two trials' worth: 2 * 3 * frames in flight + 2 * frames in flight = 24 frames; 18 is widened to that)
     import socket
     from relativisticraytracer_amd import build
     exe = build.build_headless()
-    base = ["--width", "160", "--height", "90", "--frames", "40", "--path", "0", "--spin", "0.9", "--workspace-gib", "1"]
+    base = ["--width", "160", "--height", "90", "--frames", "48", "--path", "0", "--spin", "0.9", "--workspace-gib", "1"]
     want = tmp_path / "want.rgba"
     r = subprocess.run([exe] + base + ["--path-window", "-1", "--out", str(want)], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -281,7 +282,7 @@ def test_path_choice_changes_no_byte(tmp_path):
         r = subprocess.run([exe] + base + extra + ["--out", str(out)], capture_output=True, text=True, timeout=240)
         assert r.returncode == 0, r.stderr[-2000:]
         pc = json.loads(r.stdout.strip().splitlines()[-1])["path_choice"]
-        assert len(pc) == 1 and pc[0]["frames_three_pass"] + pc[0]["frames_single_kernel"] == 40
+        assert len(pc) == 1 and pc[0]["frames_three_pass"] + pc[0]["frames_single_kernel"] == 48
         assert pc[0]["trials"] >= 1 and pc[0]["frames_single_kernel"] >= 1, pc      # (frames this small are noisy: a trial may end on an outlier)
         assert open(out, "rb").read() == open(want, "rb").read(), extra
     # one frame at a time: nothing to choose (the three-pass path's two chains are the answer there)

@@ -1,6 +1,7 @@
 """The per-window path choice of the animation drivers (include/rrt.h: rrt_path_chooser_*, csrc/rrt_path_chooser.cpp):
-host logic only -- runs without a GPU.  A synthetic rank reports sustained frame times of the two paths with the lag the
-drivers have (a frame's time is known `frames in flight` frames after it was enqueued)."""
+host logic only -- runs without a GPU.  A synthetic rank reports the intervals between consecutive frames' render ends for the two
+paths with the lag the drivers have (a frame's interval is known `frames in flight` frames after it was enqueued); on hardware the
+rule is measured by tools/chooser_probe.py (profiles/r06_chooser_probe.txt)."""
 import random
 
 import pytest
@@ -26,33 +27,44 @@ def drive(single_ms, three_pass_ms, frames=400, slots=3, window=0, noise=0.03, s
 
 def test_first_window_measures_the_three_pass_path_then_trials_start():
     _, st, pol = drive(lambda k: 5.0, lambda k: 5.0, frames=60)
-    assert pol[:10] == [0] * 10                      # 2 * frames in flight + 4 frames, no trial
-    assert pol[10:16] == [1] * 6                     # the second window opens with the trial: frames in flight + 3 frames
-    assert st["trials"] >= 1 and st["frames_single_kernel"] >= 6
+    assert pol[:13] == [0] * 13                      # 4 * frames in flight + 1 frames, no trial
+    assert pol[13:25] == [1] * 12 and pol[25] == 0   # the second window opens with the trial: 4 * frames in flight frames
+    assert st["trials"] >= 1 and st["frames_single_kernel"] >= 12
 
 
 def test_keeps_the_single_kernel_where_it_sustains_faster_frames():
-    """bench-like share (profiles/r05_sustained_chains.txt: 4.56 against 4.74 ms): within 1 % of the better path."""
-    mean, st, _ = drive(lambda k: 4.56, lambda k: 4.74)
+    """a share on which the single kernel is 7 % faster (key 1, the skimmer: profiles/r06_chooser_probe.txt): within 2 % of it."""
+    mean, st, _ = drive(lambda k: 6.1, lambda k: 6.55)
     assert st["incumbent"] == "single kernel" and st["switches"] == 1 and st["outliers"] == 0
-    assert mean <= 4.56 * 1.012 and st["frames_single_kernel"] >= 280
+    assert mean <= 6.1 * 1.02 and st["frames_single_kernel"] >= 300
+
+
+def test_intervals_that_come_in_bursts_are_compared_by_their_mean():
+    """What the hardware does with n frames in flight on n streams (profiles/r06_chooser_probe.txt): two frames end together, then a
+    gap -- intervals of 0.4 / 0.6 / 2.0 of their mean, period n.  Medians and a per-frame outlier rule (the first version) took every
+    gap of a trial for a slow frame; the mean over whole periods and an outlier rule over n frames together do not."""
+    pat = [0.4, 0.6, 2.0]
+    mean, st, _ = drive(lambda k: 6.0 * pat[k % 3], lambda k: 6.55 * pat[k % 3])
+    assert st["incumbent"] == "single kernel" and st["outliers"] == 0 and st["trials_aborted"] == 0 and mean <= 6.0 * 1.03
+    mean, st, _ = drive(lambda k: 6.9 * pat[k % 3], lambda k: 6.2 * pat[k % 3])
+    assert st["incumbent"].startswith("automatic") and st["switches"] == 0 and st["outliers"] == 0 and mean <= 6.2 * 1.02
 
 
 def test_a_long_wavefront_ends_the_experiment_at_once():
     """grazing share: single-kernel frames at 7.5 ms with every fifth at 19 (a slot waits for one long wavefront) against the
-    three-pass path's flat 6.2: the single kernel is tried, dropped on the first slow frame, tried again ever more rarely."""
+    three-pass path's flat 6.2: the single kernel is tried, dropped on the first slow stretch, tried again ever more rarely."""
     mean, st, pol = drive(lambda k: 7.5 if k % 5 else 19.0, lambda k: 6.2)
     assert st["incumbent"].startswith("automatic") and st["switches"] == 0
     assert st["trials_aborted"] == st["trials"] >= 2 and st["outliers"] >= st["trials_aborted"]
-    assert st["frames_single_kernel"] <= 24 and mean <= 6.2 * 1.03          # the price of looking: < 3 %
+    assert st["frames_single_kernel"] <= 30 and mean <= 6.2 * 1.05          # the price of looking: < 5 % (three trials in 400 frames)
     gaps = [i for i in range(1, len(pol)) if pol[i] == 1 and pol[i - 1] == 0]
     assert all(b - a >= 90 for a, b in zip(gaps, gaps[1:]))                   # back-off: the next trial two windows later, then four
 
 
-def test_a_single_kernel_that_turns_slow_is_found_within_a_window():
+def test_a_single_kernel_that_turns_slow_is_found_within_two_windows():
     mean, st, pol = drive(lambda k: 6.2 if k < 200 else 9.0, lambda k: 6.6)
     assert st["switches"] == 2 and st["incumbent"].startswith("automatic")
-    assert sum(pol[199 + 100:]) <= 12                # a hundred frames after the change the three-pass path has taken over
+    assert sum(pol[199 + 100:]) <= 12                # a hundred frames after the change only a trial still runs the single kernel
     assert mean <= 6.4 * 1.08                        # ideal: 6.2 then 6.6
 
 
@@ -64,7 +76,7 @@ def test_the_incumbent_single_kernel_is_demoted_by_an_outlier_before_its_window_
 
 def test_no_preference_without_a_difference():
     _, st, _ = drive(lambda k: 6.0, lambda k: 6.0)
-    assert st["switches"] == 0 and st["incumbent"].startswith("automatic")   # hysteresis: 3 % or nothing
+    assert st["switches"] == 0 and st["incumbent"].startswith("automatic")   # hysteresis: 4 % or nothing
 
 
 def test_arguments_and_handles():
