@@ -6,7 +6,7 @@
 //
 //   rrt_headless --width 1000 --height 700 --frames 24 --path 0 --spin 0.9 --out frames.rgba [--sky-seed 1]
 //                [--gpus N] [--tile-rows 16] [--workspace-gib G] [--noise-table-gib B | --no-noise-table]
-//                [--arith strict|fmad|fast] [--path-window F | --path-window -1]
+//                [--arith strict|fmad|fast] [--path-window F | --path-window -1 | --path-policy auto|single|three-pass]
 //                [--init-timeout 300] [--frame-timeout 120]      (watchdog, seconds; exit status 3 when it fires)
 //
 // Noise tables: the reference's simTime runs without bound (main.cpp:515) and a table's size grows with the times
@@ -202,6 +202,7 @@ struct Device {                // everything one GPU owns
 int main(int argc, char** argv) {
     int w = 1000, h = 700, frames = 24, fps = 24, path = -1, sky_seed = 1, all_fx = 0;   // config.h:7-9
     int arith = RRT_ARITH_STRICT;  // --arith strict | fmad | fast (--fast = --arith fast)
+    int path_policy = -1;          // --path-policy auto|single|three-pass pins rrt_params.path_policy for every launch (no per-window choice)
     int path_window = 0;           // frames per window of the per-rank path choice (0: the library's default, 48); -1: no choice, the
                                    // three-pass path for every small share as in rounds 1-5
     int gpus = 1, tile_rows = 16, workspace_gib = 2, use_table = 1, force_collective = 0;
@@ -230,6 +231,12 @@ int main(int argc, char** argv) {
         else if (a == "--out" && i + 1 < argc) out_path = argv[++i];
         else if (a == "--all-effects") all_fx = 1; else if (a == "--fast") arith = RRT_ARITH_FAST;
         else if (a == "--path-window") val(path_window);
+        else if (a == "--path-policy" && i + 1 < argc) {
+            const std::string m = argv[++i];
+            if (m == "auto") path_policy = RRT_PATH_AUTO; else if (m == "single") path_policy = RRT_PATH_SINGLE; else if (m == "three-pass") path_policy = RRT_PATH_THREE_PASS;
+            else { fprintf(stderr, "--path-policy auto | single | three-pass\n"); return 2; }
+            path_window = -1;
+        }
         else if (a == "--arith" && i + 1 < argc) {
             const std::string m = argv[++i];
             if (m == "strict") arith = RRT_ARITH_STRICT; else if (m == "fmad") arith = RRT_ARITH_FMAD; else if (m == "fast") arith = RRT_ARITH_FAST;
@@ -442,6 +449,7 @@ int main(int argc, char** argv) {
             // of a window, keeps it where it sustains the faster frames, and drops it at once on a frame that takes > 1.5 x the
             // three-pass median (same bytes either way)
             if (D.chooser) { int pol = RRT_PATH_AUTO; rrt_path_chooser_policy(D.chooser, k, &pol); prm.path_policy = pol; }
+            else if (path_policy >= 0) prm.path_policy = path_policy;
             void* dst = collective ? D.tiles[slot] : frame[slot];
             if (collective) rc = rrt_launch_raymarch_tiles(dst, w, h, tile_rows, d, gpus, sim_t, &cam, D.sky, &fx, &prm, D.stream[slot]);
             else rc = rrt_launch_raymarch(dst, w, h, sim_t, &cam, D.sky, &fx, &prm, D.stream[slot]);

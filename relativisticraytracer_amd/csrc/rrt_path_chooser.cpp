@@ -9,26 +9,34 @@
 // the animation drivers' camera moves: so each rank measures.  bench.py (fixed camera) does it once at start-up; the two
 // headless drivers ask this object per frame.
 //
-// Rule (per rank; the bytes do not depend on it):
-//   - the sequence is cut into windows of `window_frames` frames; the INCUMBENT path renders a window, except for a TRIAL
-//     of the other path at the window's start, 4 x frames_in_flight frames long, of which the first `frames_in_flight`
-//     overlap the other path's frames and are not counted; the same number of incumbent frames after the trial is skipped
-//     for the same reason;
+// Rule (per rank; the bytes do not depend on it).  S = frames in flight, T = 4 S (a trial), C = T - S (its counted frames):
+//   - the sequence is cut into windows of `window_frames` frames.  The INCUMBENT path renders a window, except for a TRIAL of
+//     the other path over its first T frames.  Frames whose neighbours in flight ran the other path are not counted: the first
+//     S frames of the trial and the S frames after it;
 //   - what is reported is a frame's interval on the rank: the time between the ends of consecutive frames' renders (with
-//     frames in flight a frame's own start-to-end latency says nothing).  With n frames in flight on n streams these
-//     intervals come in a pattern of period n (two frames end together, then a gap: measured, profiles/r06_chooser_probe.txt
-//     -- the first version compared medians and took every other gap for an outlier), so what is COMPARED is the mean over a
-//     multiple of n counted frames = elapsed time / frames, i.e. the sustained throughput of the path;
-//   - the first window is short (4 x frames_in_flight + 1 frames) and has no trial: it measures the three-pass path;
-//   - at the end of a window the path with the lower mean becomes the incumbent, if it wins by 4 % (hysteresis; the mean of nine
-//     frames of a rank's share is good to about 2 %); a single kernel that does not win is tried again after 2, then 4 windows; with the
-//     single kernel as incumbent every second window has its (three-pass) trial, so a single kernel that has become slow
-//     is found within two windows;
-//   - `frames_in_flight` consecutive single-kernel frames that together take more than `outlier` (1.5) x as long as the
-//     three-pass path's mean ends a trial of the single kernel at once -- or, if the single kernel is the incumbent, hands
-//     the rest of the window to the three-pass path -- and doubles the distance to the next trial (up to every 8th window).
-// The reports arrive late (a frame's interval is known once it has been delivered, frames_in_flight frames after it was
-// enqueued); the rule only needs them before the window ends.
+//     frames in flight a frame's own start-to-end latency says nothing).  With S frames in flight on S streams these intervals
+//     come in a pattern of period S (two frames end together, then a gap: measured, profiles/r06_chooser_probe.txt -- the
+//     first version compared medians and took every other gap for an outlier), so what is COMPARED are means over C = 3 S
+//     frames = elapsed time per frame, i.e. the sustained throughput of a path;
+//   - the camera MOVES, so a trial is compared with the incumbent's frames on BOTH sides of it: block A = the last C counted
+//     incumbent frames before the trial, block B = the first C after it; the incumbent's figure is (mean A + mean B) / 2, which
+//     cancels a workload that drifts linearly across the 2-3 T frames involved (the second version compared the trial with the
+//     REST of the window: on the reference's moving paths it flapped and lost 5 %: LABNOTES round 6);
+//   - the decision is taken as soon as block B is in: the other path becomes the incumbent, from the next frame on, if it wins
+//     by 4 % (hysteresis: the mean of nine frames of a rank's share is good to about 2 %).  A single kernel that did not win is
+//     tried again after 2, then 4 windows; an incumbent single kernel is checked every second window;
+//   - the first window is short (T + 1 frames), three-pass only, no trial: it supplies the first block A and the reference of
+//     the outlier rule;
+//   - S consecutive single-kernel frames that together take more than `outlier` (2.5) x as long as the reference (the three-pass
+//     path's last mean; for an incumbent single kernel also its own recent mean: an outlier is a jump, not the drift of a moving
+//     camera -- at 1.5 x of a stale three-pass mean the rule demoted a healthy single kernel on the Horizon Skimmer path) end a
+//     trial of the single kernel at once -- or, if the single kernel is the incumbent, hand the rest of the window to the
+//     three-pass path -- and double the distance to the next trial (up to every 8th window).  It is a guard against a share
+//     that suddenly holds a wavefront longer than the frames in flight together; the ordinary case of a slower path is decided
+//     by the means;
+//   - a three-pass trial that loses by more than 10 % makes the next one rarer too (every 4th, then 8th window): its 12 frames
+//     are the expensive ones where the single kernel is far ahead.
+// The reports arrive late (a frame's interval is known once it has been delivered, S frames after it was enqueued).
 #include <algorithm>
 #include <mutex>
 #include <new>
@@ -39,21 +47,24 @@
 namespace {
 
 struct Chooser {
-    int slots = 3, window = 48, trial = 6;
-    float outlier = 1.5f, hysteresis = 0.96f;
+    int slots = 3, window = 48, trial = 12, counted = 9;
+    float outlier = 2.5f, hysteresis = 0.96f;
     int incumbent = RRT_PATH_AUTO;
     int win_start = 1;               // first frame of the current window
     int win_index = 0;               // windows begun
+    int first_window = 13;           // frames of the first window
     int trial_every = 1;             // incumbent three-pass: a trial of the single kernel at the start of every `trial_every`-th window
     int since_trial = 0;
-    int first_window = 10;           // frames of the first window
     bool trial_on = false;           // this window has (had) a trial
-    bool trial_aborted = false;
+    bool trial_aborted = false, decided = false;
     int trial_end = 0;               // first frame after the trial
+    int trial_policy = RRT_PATH_SINGLE;
     bool demoted = false;            // the incumbent single kernel lost the rest of this window to the three-pass path
     int demoted_from = 0;
+    int clean_from = 1;              // incumbent frames from here on have only incumbent neighbours in flight
     std::vector<int8_t> policy_of;   // policy_of[frame % size]
-    std::vector<float> ms[2];        // this window's counted intervals per policy (index: 0 = AUTO / three-pass, 1 = SINGLE)
+    std::vector<float> tail;         // the last `counted` clean incumbent intervals (block A of the next trial)
+    std::vector<float> block_a, trial_ms, block_b;
     float recent_ms[16] = {};        // the last `slots` reports, if they were consecutive single-kernel frames (the outlier rule)
     int recent_n = 0, recent_last = 0;
     rrt_path_chooser_stats st = {};
@@ -77,37 +88,46 @@ float mean(const std::vector<float>& v) {
 void begin_window(Chooser& c, int frame) {
     c.win_start = frame;
     ++c.win_index;
-    // the first window (a short one: create()) renders with the three-pass path only: the outlier rule needs its mean.
-    // With the single kernel as incumbent every SECOND window has its (three-pass) trial -- 12 frames in 96 at the slower path,
-    // and a single kernel that has become slow without tripping the outlier rule stays for two windows at most; trials OF
-    // the single kernel back off after a lost or aborted one.
-    c.trial_on = c.win_index > 1 && ++c.since_trial >= (c.incumbent == RRT_PATH_SINGLE ? 2 : c.trial_every);
+    // the first window renders with the three-pass path only.  With the single kernel as incumbent every SECOND window has its
+    // (three-pass) trial; trials OF the single kernel back off after one it did not win or that was aborted.
+    c.trial_on = c.win_index > 1 && ++c.since_trial >= (c.incumbent == RRT_PATH_SINGLE ? std::max(2, c.trial_every) : c.trial_every);
     if (c.trial_on) c.since_trial = 0;
     c.trial_aborted = false;
+    c.decided = false;
+    c.trial_policy = c.incumbent == RRT_PATH_SINGLE ? RRT_PATH_AUTO : RRT_PATH_SINGLE;
     c.trial_end = frame + (c.trial_on ? c.trial : 0);
-    c.demoted = false;
-    c.recent_n = 0;
-    c.ms[0].clear(); c.ms[1].clear();
-    if (c.trial_on) ++c.st.trials;
-}
-
-void close_window(Chooser& c) {
-    const int other = c.incumbent == RRT_PATH_SINGLE ? RRT_PATH_AUTO : RRT_PATH_SINGLE;
-    const std::vector<float>& inc = c.ms[c.incumbent == RRT_PATH_SINGLE ? 1 : 0];
-    const std::vector<float>& alt = c.ms[other == RRT_PATH_SINGLE ? 1 : 0];
     if (c.demoted) {                                  // the single kernel met a wavefront that outlasts the frames in flight
         c.incumbent = RRT_PATH_AUTO;
         ++c.st.switches;
-        return;
+        c.demoted = false;
+        c.tail.clear();
+        c.trial_on = false;
+        c.trial_end = frame;
+        c.clean_from = frame + c.slots;
     }
-    if (!c.trial_on || c.trial_aborted || inc.size() < (size_t)c.slots || alt.size() < (size_t)c.slots) return;
-    const float mi = mean(inc), ma = mean(alt);
-    if (ma < c.hysteresis * mi) {
-        c.incumbent = other;
+    c.recent_n = 0;
+    c.block_a = c.tail;
+    c.trial_ms.clear(); c.block_b.clear();
+    if (c.trial_on) { ++c.st.trials; c.clean_from = c.trial_end + c.slots; }
+}
+
+// the trial against the incumbent's frames on both sides of it
+void decide(Chooser& c) {
+    c.decided = true;
+    if (c.trial_aborted || c.trial_ms.size() < (size_t)c.slots || c.block_b.size() < (size_t)c.slots) return;
+    const float alt = mean(c.trial_ms);
+    const float inc = c.block_a.size() >= (size_t)c.slots ? 0.5f * (mean(c.block_a) + mean(c.block_b)) : mean(c.block_b);
+    if (alt < c.hysteresis * inc) {
+        c.incumbent = c.trial_policy;
         ++c.st.switches;
         c.trial_every = 1;
+        c.tail.clear();                               // intervals of the old incumbent say nothing about the new one
     } else if (c.incumbent == RRT_PATH_AUTO) {
         c.trial_every = std::min(4, c.trial_every * 2);       // the single kernel did not win: look again in two windows, then in four
+    } else if (alt > 1.10f * inc) {
+        c.trial_every = std::min(8, std::max(2, c.trial_every) * 2);    // the three-pass path lost by > 10 %: its trials (12 slow frames) get rarer
+    } else {
+        c.trial_every = 2;
     }
 }
 
@@ -121,9 +141,11 @@ int rrt_path_chooser_create(int frames_in_flight, int window_frames, int* out_id
     if (!c) return RRT_ERR_OUT_OF_MEMORY;
     c->slots = frames_in_flight;
     c->trial = 4 * frames_in_flight;
+    c->counted = c->trial - frames_in_flight;
     c->window = window_frames > 0 ? window_frames : 48;
-    if (c->window < 2 * c->trial + 2 * c->slots) c->window = 2 * c->trial + 2 * c->slots;      // room for counted frames of both paths
-    c->first_window = 4 * frames_in_flight + 1;
+    const int least = c->trial + c->slots + 2 * c->counted;        // trial, its wake, block B, and a block A for the next window
+    if (c->window < least) c->window = least;
+    c->first_window = c->trial + 1;
     c->policy_of.assign(1024, (int8_t)RRT_PATH_AUTO);
     std::lock_guard<std::mutex> lk(g_mu);
     g_choosers.push_back(c);
@@ -147,10 +169,12 @@ int rrt_path_chooser_policy(int id, int frame, int* policy_out) {
     if (!c) return RRT_ERR_BAD_HANDLE;
     if (!policy_out || frame < 1) return RRT_ERR_INVALID_ARGUMENT;
     if (c->win_index == 0) begin_window(*c, frame);
-    else if (frame >= c->win_start + (c->win_index == 1 ? c->first_window : c->window)) { close_window(*c); begin_window(*c, frame); }
-    const int other = c->incumbent == RRT_PATH_SINGLE ? RRT_PATH_AUTO : RRT_PATH_SINGLE;
+    else if (frame >= c->win_start + (c->win_index == 1 ? c->first_window : c->window)) {
+        if (c->trial_on && !c->decided) decide(*c);              // the reports of block B came late: decide on what is there
+        begin_window(*c, frame);
+    }
     int p = c->incumbent;
-    if (c->trial_on && !c->trial_aborted && frame < c->trial_end) p = other;
+    if (c->trial_on && !c->trial_aborted && frame < c->trial_end) p = c->trial_policy;
     if (c->demoted && frame >= c->demoted_from) p = RRT_PATH_AUTO;
     c->policy_of[(size_t)frame % c->policy_of.size()] = (int8_t)p;
     ++c->st.frames[p == RRT_PATH_SINGLE ? 1 : 0];
@@ -158,7 +182,7 @@ int rrt_path_chooser_policy(int id, int frame, int* policy_out) {
     return RRT_OK;
 }
 
-/* the sustained time of frame `frame` on this rank: milliseconds between the end of frame `frame - 1`'s render and its own */
+/* the interval of frame `frame` on this rank: milliseconds between the end of frame `frame - 1`'s render and its own */
 int rrt_path_chooser_report(int id, int frame, float ms) {
     std::lock_guard<std::mutex> lk(g_mu);
     Chooser* c = get(id);
@@ -166,18 +190,23 @@ int rrt_path_chooser_report(int id, int frame, float ms) {
     if (frame < 1 || !(ms >= 0.0f)) return RRT_ERR_INVALID_ARGUMENT;
     if (c->win_index == 0 || frame < c->win_start) return RRT_OK;              // a report of an earlier window: too late to matter
     const int p = c->policy_of[(size_t)frame % c->policy_of.size()];
-    // frames whose neighbours in flight ran the other path do not count: the first `slots` of a window (its trial, or the frames
-    // after the previous window's) and the first `slots` after the trial
-    const int rel = frame - c->win_start;
     const bool in_trial = c->trial_on && frame < c->trial_end;
-    const bool mixed = rel < c->slots || (c->trial_on && !in_trial && frame < c->trial_end + c->slots);
-    if (p == RRT_PATH_SINGLE && !mixed) {
-        // the outlier rule on `slots` consecutive single-kernel frames together (one period of the interval pattern)
+    const bool trial_counted = in_trial && frame >= c->win_start + c->slots && p == c->trial_policy;
+    const bool clean_incumbent = !in_trial && frame >= c->clean_from && p == c->incumbent && !(c->demoted && frame >= c->demoted_from);
+    // ---- the outlier rule on `slots` consecutive clean single-kernel frames together (one period of the interval pattern)
+    if (p == RRT_PATH_SINGLE && (trial_counted || clean_incumbent)) {
         if (c->recent_n > 0 && frame != c->recent_last + 1) c->recent_n = 0;
         if (c->recent_n == c->slots) { for (int i = 1; i < c->slots; ++i) c->recent_ms[i - 1] = c->recent_ms[i]; --c->recent_n; }
         c->recent_ms[c->recent_n++] = ms;
         c->recent_last = frame;
-        const float ref = c->ms[0].size() >= (size_t)c->slots ? mean(c->ms[0]) : c->st.last_three_pass_mean_ms;
+        // reference: the three-pass path's last mean, or -- the workload of an animation drifts, and a mean measured a window ago
+        // may be half of today's -- the single kernel's own recent mean if that is larger: an outlier is a JUMP, not a drift
+        float ref = c->st.last_three_pass_mean_ms;
+        if (c->incumbent == RRT_PATH_SINGLE && c->tail.size() >= (size_t)(2 * c->slots)) {
+            // (the tail WITHOUT its last `slots` entries: those may be the very frames under test)
+            const std::vector<float> older(c->tail.begin(), c->tail.end() - c->slots);
+            ref = std::max(ref, mean(older));
+        }
         if (c->recent_n == c->slots && ref > 0.0f) {
             float sum = 0.0f;
             for (int i = 0; i < c->slots; ++i) sum += c->recent_ms[i];
@@ -185,7 +214,10 @@ int rrt_path_chooser_report(int id, int frame, float ms) {
                 ++c->st.outliers;
                 c->recent_n = 0;
                 if (c->incumbent != RRT_PATH_SINGLE) {              /* trial frames (the report may arrive after the trial's last frame) */
-                    if (!c->trial_aborted) { c->trial_aborted = true; ++c->st.trials_aborted; c->trial_every = std::min(8, c->trial_every * 2); }
+                    if (!c->trial_aborted && !c->decided) {
+                        c->trial_aborted = true; ++c->st.trials_aborted; c->trial_every = std::min(8, c->trial_every * 2);
+                        c->clean_from = frame + 1 + 2 * c->slots;   /* single-kernel frames already enqueued drain first */
+                    }
                 } else if (!c->demoted) {
                     c->demoted = true;
                     c->demoted_from = frame + 1;
@@ -197,10 +229,19 @@ int rrt_path_chooser_report(int id, int frame, float ms) {
     } else if (p != RRT_PATH_SINGLE) {
         c->recent_n = 0;
     }
-    if (!mixed) {
-        c->ms[p == RRT_PATH_SINGLE ? 1 : 0].push_back(ms);
-        if (p != RRT_PATH_SINGLE && c->ms[0].size() >= (size_t)c->slots) c->st.last_three_pass_mean_ms = mean(c->ms[0]);
+    // ---- the samples
+    if (trial_counted) {
+        if ((int)c->trial_ms.size() < c->counted) c->trial_ms.push_back(ms);
+    } else if (clean_incumbent) {
+        if (c->trial_on && !c->decided && (int)c->block_b.size() < c->counted) c->block_b.push_back(ms);
+        c->tail.push_back(ms);
+        if ((int)c->tail.size() > c->counted) c->tail.erase(c->tail.begin());
     }
+    if (p != RRT_PATH_SINGLE && (trial_counted || clean_incumbent)) {
+        const std::vector<float>& v = trial_counted ? c->trial_ms : c->tail;
+        if (v.size() >= (size_t)c->slots) c->st.last_three_pass_mean_ms = mean(v);
+    }
+    if (c->trial_on && !c->decided && !c->trial_aborted && (int)c->trial_ms.size() >= c->counted && (int)c->block_b.size() >= c->counted) decide(*c);
     return RRT_OK;
 }
 

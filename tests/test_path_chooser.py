@@ -50,15 +50,42 @@ def test_intervals_that_come_in_bursts_are_compared_by_their_mean():
     assert st["incumbent"].startswith("automatic") and st["switches"] == 0 and st["outliers"] == 0 and mean <= 6.2 * 1.02
 
 
-def test_a_long_wavefront_ends_the_experiment_at_once():
+def test_a_moving_camera_does_not_fool_the_comparison():
+    """The workload of an animation drifts from frame to frame (a fly-by: +- 40 % over a few hundred frames), the same for both
+    paths.  A trial is therefore compared with the incumbent's frames on BOTH sides of it (the version that compared it with the
+    rest of its window flapped on the reference's paths at 1000x700 and lost 5 %: profiles/r06_window_paths_chooser.txt)."""
+    import math
+    drift = lambda k: 1.0 + 0.4 * math.sin(k / 50.0)
+    _, st, _ = drive(lambda k: drift(k) * 5.40, lambda k: drift(k) * 5.13)              # three-pass 5 % faster throughout
+    assert st["incumbent"].startswith("automatic") and st["switches"] == 0
+    mean, st, _ = drive(lambda k: drift(k) * 7.45, lambda k: drift(k) * 9.0)            # single kernel 17 % faster throughout
+    assert st["incumbent"] == "single kernel" and st["switches"] == 1
+    _, st, _ = drive(lambda k: 5.0 + 0.02 * k, lambda k: 5.0 + 0.02 * k)                # a steady ramp, no difference between the paths
+    assert st["switches"] == 0
+
+
+def test_a_path_that_is_slower_on_average_loses_its_trials():
     """grazing share: single-kernel frames at 7.5 ms with every fifth at 19 (a slot waits for one long wavefront) against the
-    three-pass path's flat 6.2: the single kernel is tried, dropped on the first slow stretch, tried again ever more rarely."""
+    three-pass path's flat 6.2 -- on hardware such a share shows as an 11-13 % slower mean (profiles/r06_chooser_probe.txt): the
+    means decide, the single kernel never becomes the incumbent, and its trials get rarer (2, then 4 windows apart)."""
     mean, st, pol = drive(lambda k: 7.5 if k % 5 else 19.0, lambda k: 6.2)
     assert st["incumbent"].startswith("automatic") and st["switches"] == 0
-    assert st["trials_aborted"] == st["trials"] >= 2 and st["outliers"] >= st["trials_aborted"]
-    assert st["frames_single_kernel"] <= 30 and mean <= 6.2 * 1.05          # the price of looking: < 5 % (three trials in 400 frames)
+    assert st["frames_single_kernel"] <= 36 and mean <= 6.2 * 1.07            # the price of looking: three trials in 400 frames
     gaps = [i for i in range(1, len(pol)) if pol[i] == 1 and pol[i - 1] == 0]
     assert all(b - a >= 90 for a, b in zip(gaps, gaps[1:]))                   # back-off: the next trial two windows later, then four
+
+
+def test_a_sudden_stall_of_the_single_kernel_ends_it_at_once():
+    """The outlier rule is a JUMP detector: `frames in flight` consecutive single-kernel frames that take > 2.5 x the reference.  As
+    a trial: aborted on the spot; as the incumbent: the rest of the window goes to the three-pass path."""
+    _, st, pol = drive(lambda k: 25.0, lambda k: 6.2)                           # every trial of the single kernel stalls
+    assert st["incumbent"].startswith("automatic") and st["trials_aborted"] == st["trials"] >= 2 and st["frames_single_kernel"] <= 36
+    _, st, pol = drive(lambda k: 5.8 if k < 150 else 25.0, lambda k: 6.2)       # the incumbent single kernel stalls at frame 150
+    assert st["incumbent"].startswith("automatic") and st["outliers"] >= 1
+    assert sum(pol[150 + 20:150 + 48]) == 0          # within 20 frames of the stall the rest of the window is three-pass
+    # ... and a workload that merely DRIFTS up four-fold within a hundred frames (a camera diving into the disk) is no outlier
+    _, st, _ = drive(lambda k: (1 + 3 * min(1.0, k / 100.0)) * 3.0, lambda k: (1 + 3 * min(1.0, k / 100.0)) * 4.1)
+    assert st["incumbent"] == "single kernel" and st["outliers"] == 0
 
 
 def test_a_single_kernel_that_turns_slow_is_found_within_two_windows():
@@ -66,12 +93,6 @@ def test_a_single_kernel_that_turns_slow_is_found_within_two_windows():
     assert st["switches"] == 2 and st["incumbent"].startswith("automatic")
     assert sum(pol[199 + 100:]) <= 12                # a hundred frames after the change only a trial still runs the single kernel
     assert mean <= 6.4 * 1.08                        # ideal: 6.2 then 6.6
-
-
-def test_the_incumbent_single_kernel_is_demoted_by_an_outlier_before_its_window_ends():
-    _, st, pol = drive(lambda k: 5.8 if k < 150 else (7.5 if k % 7 else 19.0), lambda k: 6.2)
-    assert st["incumbent"].startswith("automatic") and st["outliers"] >= 1
-    assert sum(pol[150 + 20:150 + 48]) == 0          # within 20 frames of the first slow frame the rest of the window is three-pass
 
 
 def test_no_preference_without_a_difference():
