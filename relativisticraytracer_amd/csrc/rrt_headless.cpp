@@ -4,7 +4,7 @@
 // :176-203) or the start-up camera (:128-130), launch_raymarch (:467), hand the pixels to the recorder
 // (captureFrame, :85-97 -- here a raw RGBA stream, the bytes the reference pipes into ffmpeg).
 //
-//   rrt_headless --width 1000 --height 700 --frames 24 --path 0 --spin 0.9 --out frames.rgba [--sky-seed 1]
+//   rrt_headless --width 1000 --height 700 --frames 24 --path 0 --spin 0.9 --out frames.rgba [--sky-seed 1 | --sky file.rrtsky]
 //                [--gpus N] [--tile-rows 16] [--workspace-gib G] [--noise-table-gib B | --no-noise-table]
 //                [--arith strict|fmad|fast] [--path-window F | --path-window -1 | --path-policy auto|single|three-pass]
 //                [--init-timeout 300] [--frame-timeout 120]      (watchdog, seconds; exit status 3 when it fires)
@@ -73,6 +73,27 @@ std::vector<uint8_t> synthetic_sky(int w, int h, int seed) {
             t[0] = cl(r); t[1] = cl(g); t[2] = cl(b); t[3] = 255;
         }
     return out;
+}
+
+// A raw sky (relativisticraytracer_amd/sky.py: save_sky_raw, tools/sky_to_raw.py): "RRTSKY1\n", "<width> <height>\n", then height x width
+// RGBA8 texels, row 0 = top -- the bytes the reference's stbi_load(..., 4) returns (src/main.cpp:240), decoded ONCE with the reference's
+// own decoder and shipped (JPEG decoders differ: SURVEY.md row f1).  Returns false with a message on anything else.
+bool load_sky_raw(const std::string& path, std::vector<uint8_t>& texels, int& w, int& h) {
+    FILE* fh = fopen(path.c_str(), "rb");
+    if (!fh) { fprintf(stderr, "rrt_headless: cannot open sky %s\n", path.c_str()); return false; }
+    char magic[8] = {};
+    bool ok = fread(magic, 1, 8, fh) == 8 && memcmp(magic, "RRTSKY1\n", 8) == 0;
+    char line[64] = {};
+    long long lw = 0, lh = 0;
+    ok = ok && fgets(line, sizeof(line), fh) != nullptr && sscanf(line, "%lld %lld", &lw, &lh) == 2 && lw > 0 && lh > 0 && lw * lh <= (1ll << 30);
+    if (ok) {
+        texels.resize((size_t)(lw * lh * 4));
+        ok = fread(texels.data(), 1, texels.size(), fh) == texels.size() && fgetc(fh) == EOF;
+    }
+    fclose(fh);
+    if (!ok) { fprintf(stderr, "rrt_headless: %s is not a raw sky (RRTSKY1 header, width height, RGBA8 texels)\n", path.c_str()); return false; }
+    w = (int)lw; h = (int)lh;
+    return true;
 }
 
 // Progress trace + watchdog.  Every phase of the driver passes a trace point; the last kTraceKeep of them are kept in
@@ -213,7 +234,7 @@ int main(int argc, char** argv) {
     float spin = 0.0f;
     double table_gib = 2.0;
     double init_timeout = 300.0, frame_timeout = 120.0;       // watchdog limits in seconds (0: none)
-    std::string out_path;
+    std::string out_path, sky_path;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto val = [&](int& dst) { if (i + 1 < argc) dst = atoi(argv[++i]); };
@@ -229,6 +250,7 @@ int main(int argc, char** argv) {
         else if (a == "--tile-order") tile_order = 1; else if (a == "--no-tile-order") tile_order = 0;
         else if (a == "--force-collective") force_collective = 1;     // run the RCCL exchange even with one GPU (self-check)
         else if (a == "--out" && i + 1 < argc) out_path = argv[++i];
+        else if (a == "--sky" && i + 1 < argc) sky_path = argv[++i];
         else if (a == "--all-effects") all_fx = 1; else if (a == "--fast") arith = RRT_ARITH_FAST;
         else if (a == "--path-window") val(path_window);
         else if (a == "--path-policy" && i + 1 < argc) {
@@ -275,7 +297,10 @@ int main(int argc, char** argv) {
     float win_t0 = 0.0f, win_t1 = -1.0f;         // the window the devices' tables (or the remembered failure) cover; empty at first
     bool win_has_table = false;
 
-    const std::vector<uint8_t> sky = synthetic_sky(2048, 1024, sky_seed);
+    std::vector<uint8_t> sky;
+    int sky_w = 2048, sky_h = 1024;
+    if (sky_path.empty()) sky = synthetic_sky(sky_w, sky_h, sky_seed);
+    else if (!load_sky_raw(sky_path, sky, sky_w, sky_h)) return 2;
     rrt_effects fx; rrt_effects_default(&fx);
     fx.use_chromatic_aberration = (uint8_t)all_fx;
 
@@ -294,7 +319,7 @@ int main(int argc, char** argv) {
         D.id = d;
         HIPCHK(hipSetDevice(d));
         const int rows = collective ? D.shard_rows : h;            // image rows of one launch on this device
-        if ((rc = rrt_sky_create(sky.data(), 2048, 1024, &D.sky)) != RRT_OK) return fail("sky", rc);
+        if ((rc = rrt_sky_create(sky.data(), sky_w, sky_h, &D.sky)) != RRT_OK) return fail("sky", rc);
         HIPCHK(hipMalloc(&D.probe, 256 * (size_t)(gpus + 1)));
         HIPCHK(hipEventCreateWithFlags(&D.comm_free, hipEventDisableTiming));
         // the path is a choice only where a launch could take either: a pool, a share under RRT_PATH_AUTO's threshold, frames in

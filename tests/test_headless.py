@@ -263,6 +263,35 @@ def test_both_drivers_render_the_same_fmad_frames(tmp_path):
 
 
 @pytest.mark.gpu
+def test_both_drivers_render_a_raw_sky(tmp_path):
+    """SURVEY row f1 on the C++ side (round 6): `rrt_headless --sky file` reads the raw sky format (sky.save_sky_raw: the texels the
+    reference's own decoder returned, shipped as they are) -- the same frames as the Python driver with the same file, other than
+    with the synthetic sky; a file that is not a raw sky is refused (status 2), not guessed at."""
+    from relativisticraytracer_amd import build
+    from relativisticraytracer_amd.sky import save_sky_raw
+    exe = build.build_headless()
+    rng = np.random.default_rng(7)
+    sky = rng.integers(0, 256, (96, 200, 4), dtype=np.uint8); sky[..., 3] = 255          # an odd-sized sky
+    raw = tmp_path / "sky.rrtsky"
+    save_sky_raw(str(raw), sky)
+    base = ["--width", "160", "--height", "90", "--frames", "2", "--path", "1", "--spin", "0.9", "--all-effects"]
+    outs = {}
+    for tag, cmd in (("cpp", [exe] + base + ["--sky", str(raw)]), ("cpp_synthetic", [exe] + base),
+                     ("py", [sys.executable, "-m", "relativisticraytracer_amd.headless"] + base + ["--sky", str(raw)])):
+        out = tmp_path / (tag + ".rgba")
+        r = subprocess.run(cmd + ["--out", str(out)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = open(out, "rb").read()
+    assert outs["cpp"] == outs["py"] and outs["cpp"] != outs["cpp_synthetic"]
+    bad = tmp_path / "bad.rrtsky"
+    bad.write_bytes(b"RRTSKY1\n200 96\n" + bytes(100))
+    r = subprocess.run([exe] + base + ["--sky", str(bad)], capture_output=True, text=True)
+    assert r.returncode == 2 and "not a raw sky" in r.stderr
+    r = subprocess.run([exe] + base + ["--sky", str(tmp_path / "missing")], capture_output=True, text=True)
+    assert r.returncode == 2 and "cannot open" in r.stderr
+
+
+@pytest.mark.gpu
 def test_path_choice_changes_no_byte(tmp_path):
     """Round 6: under frames in flight a small share's path is chosen per window by measurement (rrt_path_chooser).  40 frames
     of path 0 through the C++ driver -- a single device with the exchange, and without -- and through two ranks of the Python
