@@ -126,10 +126,9 @@ def main(argv=None):
                              noise_table=0, tile_order=orders[j].id if orders else 0,
                              arith_mode=arith_mode, workspace=pools[j].id if pools else 0,
                              # frames in flight fill each other's drains: ONE chain per launch (the second chain's streams only compete with
-                             # the other frames: 2-7 % per frame, profiles/r05_sustained_chains.txt).  The plain single kernel would be
-                             # faster still on most views (0.98-1.0 of a rank's fair share against 0.86-0.96) but its longest wavefront
-                             # -- up to 19 ms on a disk-grazing view -- bounds a slot's frame rate: this driver's camera moves, so it keeps
-                             # the path that is never slow (bench.py, whose camera is fixed, times both at start-up)
+                             # the other frames: 2-7 % per frame, profiles/r05_sustained_chains.txt).  Which PATH a small share takes --
+                             # the three-pass path, or the plain single kernel, which is 6-8 % faster unless the share holds a wavefront that
+                             # outlasts the frames in flight -- is chosen per window by measurement (chooser, above; round 6)
                              pass_chains=1 if n_slots >= 2 else 0,
                              path_policy=int(os.environ.get("RRT_PATH_POLICY", "0"))) for j in range(n_slots)]
     path = camera_paths.CameraPath(args.path) if args.path >= 0 else None
