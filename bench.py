@@ -10,11 +10,15 @@ full volumetric disk + dust + Doppler/redshift, the reference's start-up camera
 rank per GPU) the SAME frame is split into interleaved 16-row tiles across the ranks
 and assembled on rank 0 by one RCCL gather: strong scaling.
 
-Rank 0 prints one JSON line.  `value` = Mrays/s (= Mpixels/s) of the whole job.
+Rank 0 prints one JSON line.  `value` = Mrays/s (= Mpixels/s) of the whole job, strict arithmetic.
 `roofline` prices the dominant kernel (raymarch_pixels) against the FP32 vector-ALU
-issue rate, which is what bounds it; the HBM view that the north star
-asks for is reported alongside.  `cpu_baseline` is the CPU oracle (OpenMP) on a strided
-sample of the same frame -- a reported baseline, not a target.
+issue rate, which is what bounds it, with every timed frame's kernel time,
+the clock the chip held, the PMC view (issue-slot utilisation, HBM traffic: only from records
+measured on this build's sources); the HBM view that the north star asks for is reported
+alongside.  `cpu_baseline` is the reference's own kernel body (OpenMP, all host cores; the
+oracle port beside it) on a strided sample of the same frame, on every N -- a reported
+baseline, not a target.  `within_tolerance_mode` = RRT_ARITH_FMAD (the arithmetic class of the
+reference's own build) with its account; never `value`.
 """
 import argparse
 import json

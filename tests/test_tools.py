@@ -27,3 +27,29 @@ def test_headline_kernel_is_the_table_instantiation_not_the_arithmetic_noise_leg
     # --no-noise-table runs: the arithmetic-noise kernel IS the headline
     kind1 = _load("summarize_profile").make_kind([n % (1, "false", 0)])
     assert kind1(n % (1, "false", 0)) == "kernel"
+
+
+def test_vacuum_step_instruction_counts_from_the_listing():
+    """Round 6: the RK4 step that is taken nine times in ten carries no register copy and stays at its arithmetic
+    count -- read off the hipcc listing of the shipped flags by tools/isa_histogram.py, which walks the nested vacuum loop's straight
+    path (hipcc cross-compiles without a GPU; about a minute).  Measured: 216 VALU per FMAD step (round 5's flat loop: 235, of them 14
+    v_mov), 276 per strict step (288) -- for 297 source operations; pass 1 of the three-pass path takes the same loop."""
+    import re
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_histogram.py"), "raymarch_pixels<true, 2, false, 2>",
+                        "raymarch_pixels<true, 2, false, 0>", "march_defer<true, 0, false>"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    got = {}
+    name = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("== "):
+            name = ln[3:].strip()
+        m = re.search(r"VACUUM LOOP \(nested, body written out (\d+)x\).*?(\d+) VALU \((\d+) v_mov\) = ([0-9.]+) VALU per RK4 step", ln)
+        if m and name:
+            got[name] = (int(m.group(1)), int(m.group(3)), float(m.group(4)))
+    assert set(got) == {"raymarch_pixels<true, 2, false, 2>", "raymarch_pixels<true, 2, false, 0>", "march_defer<true, 0, false>"}, r.stdout[-1500:]
+    fmad, strict, defer = got["raymarch_pixels<true, 2, false, 2>"], got["raymarch_pixels<true, 2, false, 0>"], got["march_defer<true, 0, false>"]
+    assert fmad[0] == strict[0] == 2                                  # the body is written out twice
+    assert fmad[1] == 0 and strict[1] == 0 and defer[1] == 0          # no v_mov on the straight path
+    assert fmad[2] <= 225.0 and strict[2] <= 283.0 and defer[2] <= 283.0, got      # VERDICT r05's mark for FMAD: <= 225
